@@ -1,0 +1,300 @@
+/*
+ * rtpbr.h — C ABI of the MI355X-native SDF path-tracing sample path.
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  In the reference the boundary is the
+ * Taichi kernel launch from Python: the kernels `pathtrace()` (src/pathtracer.py:94-103),
+ * `refresh()` (src/renderer.py:12-22) and `post_process()` (src/postprocessor.py:24-43) take
+ * no arguments and read/write global Taichi fields; the examples pass the camera by value
+ * (examples/cornell_box/cornell_box_v3/renderer.py:11-42,
+ *  examples/bunny/bunny_sdf_glass.py:393-432, examples/scene_demo/tokyo_ibl.py:403-439).
+ * Here every field becomes a buffer owned by an opaque context and every kernel launch
+ * becomes one plain C function, so that a ctypes / cgo / JNI / N-API stub can bind it.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative RTPBR_E* code on failure;
+ *     rtpbr_last_error() returns a thread-local human readable message;
+ *   - host pointers passed in are copied; the caller keeps ownership;
+ *   - calls on one context are serialised on one HIP stream; different contexts
+ *     (e.g. one per GPU) are independent; a context is not thread safe;
+ *   - image buffers use the reference's field layout: dense (W, H, C) float32,
+ *     element [i][j][c] with i = column from the left, j = row from the BOTTOM,
+ *     j fastest.
+ *
+ * All structs are plain-old-data with 4-byte members only (no padding).
+ */
+#ifndef RTPBR_H
+#define RTPBR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ error codes */
+#define RTPBR_OK            0
+#define RTPBR_EINVAL       -1   /* bad argument / inconsistent state            */
+#define RTPBR_EHIP         -2   /* a HIP runtime call or kernel launch failed    */
+#define RTPBR_ENOMEM       -3   /* allocation failed                             */
+#define RTPBR_ESTATE       -4   /* call order violated (e.g. sample before scene)*/
+
+/* ------------------------------------------------------------------ shapes
+ * reference: class SHAPE(IntEnum) src/sdf.py:12-18.  RTPBR_SHAPE_BUNNY is the neural
+ * SDF of examples/bunny/bunny_sdf_glass.py:149-203 (its own file calls it SHAPE_BUNNY=1). */
+enum {
+    RTPBR_SHAPE_NONE = 0,
+    RTPBR_SHAPE_SPHERE = 1,
+    RTPBR_SHAPE_BOX = 2,
+    RTPBR_SHAPE_CYLINDER = 3,
+    RTPBR_SHAPE_CONE = 4,
+    RTPBR_SHAPE_PLANE = 5,
+    RTPBR_SHAPE_BUNNY = 6
+};
+
+#define RTPBR_MAX_OBJECTS 32
+
+/* ------------------------------------------------------------------ data model (T1..T5) */
+
+/* reference: Ray src/dataclass.py:5-10 (40 B).  depth = raycast count, its SIGN is the
+ * "finished" flag, 0 = fresh after refresh().  The examples' Ray has no depth. */
+typedef struct rtpbr_ray {
+    float   origin[3];
+    float   direction[3];
+    float   color[3];
+    int32_t depth;
+} rtpbr_ray;
+
+/* reference: Material src/dataclass.py:13-20 (40 B).  emission is MULTIPLICATIVE,
+ * (1,1,1) means "not a light". */
+typedef struct rtpbr_material {
+    float albedo[3];
+    float emission[3];
+    float roughness;
+    float metallic;
+    float transmission;
+    float ior;
+} rtpbr_material;
+
+/* reference: Transform src/dataclass.py:23-28 (72 B).  rotation = Euler DEGREES,
+ * scale = shape parameters (never a real scale), matrix = world->local rotation,
+ * row major, filled by rtpbr_set_scene() like update_transform() src/scene.py:99-103. */
+typedef struct rtpbr_transform {
+    float position[3];
+    float rotation[3];
+    float scale[3];
+    float matrix[9];
+} rtpbr_transform;
+
+/* reference: SDFObject src/dataclass.py:31-35 (116 B). */
+typedef struct rtpbr_object {
+    int32_t         type;
+    rtpbr_transform transform;
+    rtpbr_material  material;
+} rtpbr_object;
+
+/* reference: Camera src/dataclass.py:38-46 (52 B); vfov in degrees. */
+typedef struct rtpbr_camera {
+    float lookfrom[3];
+    float lookat[3];
+    float vup[3];
+    float vfov;
+    float aspect;
+    float aperture;
+    float focus;
+} rtpbr_camera;
+
+/* ------------------------------------------------------------------ variant knobs
+ * One field per row of SURVEY.md Appendix B.  The reference fixes these as Python module
+ * constants consumed through ti.static at JIT time (src/config.py:7-28 and the constant
+ * block at the top of every example); here they are runtime values of one POD struct. */
+
+enum { RTPBR_FORM_COMPLETE_PATH = 0,   /* examples: for i in range(MAX_RAYTRACE) inside the kernel */
+       RTPBR_FORM_PERSISTENT_RAY = 1 };/* src/: one bounce-step per launch, state in ray_buffer   */
+
+enum { RTPBR_MARCH_PLAIN = 0,          /* cornell_box.py:213-223, cornell_box_v2.py:186-196, shortest:63-72 */
+       RTPBR_MARCH_RELAXED = 1,        /* cornell_box_v3/pathtracer.py:52-78 (err = d/t), tokyo, bunny      */
+       RTPBR_MARCH_SRC = 2 };          /* src/scene.py:59-84 (origin moves, d < t*PIXEL_RADIUS)             */
+
+enum { RTPBR_NORMAL_WORLD = 0,         /* examples: offsets in world space                   */
+       RTPBR_NORMAL_LOCAL = 1 };       /* src/sdf.py:77-87: local frame, not rotated back    */
+
+enum { RTPBR_RR_EXAMPLES = 0,          /* p = 1-exp(-i/light_quality); "kill" = color*=p, keep */
+       RTPBR_RR_SRC = 1 };             /* p = (depth==0?1:q) - depth/MAX_RAYTRACE; kill = 0    */
+
+enum { RTPBR_FRESNEL_C2 = 0,           /* F0=(e-1)/(e+1); F0*=2*F0  (cornell v1/v2/v3, bunny)  */
+       RTPBR_FRESNEL_C4 = 1 };         /* F0=2(e-1)/(e+1); F0*=F0   (src, scene_demo, tokyo)   */
+
+enum { RTPBR_HORIZON_KILL = 0,         /* examples: color *= (dot(D,n) > 0)                    */
+       RTPBR_HORIZON_FLIP = 1 };       /* src/pbr.py:50-51: D = -D                             */
+
+enum { RTPBR_ORIGIN_HIT = 0,           /* examples: origin = hit position                      */
+       RTPBR_ORIGIN_OFFSET = 1 };      /* src/pbr.py:59-60: origin += +-n*MIN_DIS              */
+
+enum { RTPBR_SURFACE_FULL = 0,
+       RTPBR_SURFACE_DIFFUSE = 1 };    /* cornell_box_shortest.py:91-94                        */
+
+enum { RTPBR_SKY_BLACK = 0,            /* cornell: miss => color = 0                           */
+       RTPBR_SKY_ENVMAP = 1,           /* src/ibl.py:36-40, tokyo, bunny                       */
+       RTPBR_SKY_GRADIENT = 2 };       /* scene_demo/main.py:245-248                           */
+
+enum { RTPBR_PRIMARY_AS_SKY = 0,
+       RTPBR_PRIMARY_BLACK = 1,        /* src BLACK_BACKGROUND, bunny_sdf.py:352               */
+       RTPBR_PRIMARY_WHITE = 2 };      /* bunny_sdf_v2.py:355-356                              */
+
+enum { RTPBR_TONEMAP_GAMMA_ACES_CLAMP = 0,  /* src, shortest, v3                               */
+       RTPBR_TONEMAP_ACES_GAMMA = 1,        /* v1, v2                                          */
+       RTPBR_TONEMAP_ACES_CLAMP_GAMMA = 2,  /* bunny*                                          */
+       RTPBR_TONEMAP_ACES_GAMMA_CLAMP = 3 };/* tokyo, scene_demo                               */
+
+enum { RTPBR_CAMERA_THIN_LENS = 0,     /* src/camera.py:11-36                                  */
+       RTPBR_CAMERA_PINHOLE = 1 };     /* cornell_box_shortest.py:107-118 (no lens draws)      */
+
+typedef struct rtpbr_config {
+    int32_t  width, height;        /* image_resolution                                        */
+    uint32_t seed;                 /* counter-based RNG seed                                  */
+    int32_t  kernel_form;          /* RTPBR_FORM_*                                            */
+    int32_t  max_raymarch;         /* MAX_RAYMARCH                                            */
+    int32_t  max_raytrace;         /* MAX_RAYTRACE                                            */
+    /* sphere tracing */
+    int32_t  march_kind;           /* RTPBR_MARCH_*                                           */
+    float    min_dis;              /* examples: march start t0; src: normal offset MIN_DIS    */
+    float    max_dis;              /* MAX_DIS                                                 */
+    float    hit_eps;              /* PRECISION (plain) or PIXEL_RADIUS (relaxed / src)       */
+    float    omega0;               /* initial over-relaxation                                 */
+    int32_t  omega_guard;          /* 1: fall back only while omega > 1                       */
+    float    omega_fb_a, omega_fb_b; /* on overshoot: omega <- a + b*omega                    */
+    /* sdf */
+    float    box_round;            /* rounding rho of sd_box                                  */
+    int32_t  nearest_init;         /* 0: start from object 0 (cornell_box_v3/pathtracer.py:41-49)
+                                      1: start from (0, MAX_DIS) (src/scene.py:45-46, tokyo_ibl.py:222) */
+    /* normal */
+    float    normal_h;
+    int32_t  normal_space;         /* RTPBR_NORMAL_*                                          */
+    /* russian roulette */
+    int32_t  rr_kind;              /* RTPBR_RR_*                                              */
+    float    light_quality;        /* examples                                                */
+    float    quality_per_sample;   /* src QUALITY_PER_SAMPLE                                  */
+    /* surface model */
+    int32_t  surface_kind;         /* RTPBR_SURFACE_*                                         */
+    int32_t  fresnel_kind;         /* RTPBR_FRESNEL_*                                         */
+    int32_t  fresnel_roughness_mix;/* examples 1, src 0                                       */
+    int32_t  below_horizon;        /* RTPBR_HORIZON_*                                         */
+    int32_t  origin_mode;          /* RTPBR_ORIGIN_*                                          */
+    float    env_ior;              /* ENV_IOR                                                 */
+    /* miss / sky */
+    int32_t  sky_kind;             /* RTPBR_SKY_*                                             */
+    int32_t  primary_miss;         /* RTPBR_PRIMARY_*                                         */
+    /* stop test: stop if brighter, or visible < vis_lo, or visible > vis_hi */
+    float    vis_lo, vis_hi;
+    /* camera */
+    int32_t  camera_kind;          /* RTPBR_CAMERA_*                                          */
+    /* tone map */
+    int32_t  tonemap_order;        /* RTPBR_TONEMAP_*                                         */
+    int32_t  aces_truncated;       /* 1: cornell_box_shortest.py:126-128 literals             */
+    float    exposure;
+    float    gamma;
+    /* animation uniform (u_frame, bunny_sdf_glass.py:213-217) */
+    int32_t  frame;
+    /* persistent-ray form: bounce-steps per pixel per launch (SAMPLES_PER_PIXEL) */
+    int32_t  steps_per_launch;
+} rtpbr_config;
+
+/* ------------------------------------------------------------------ buffers */
+enum { RTPBR_BUF_IMAGE_BUFFER = 0,   /* T7 image_buffer  (W,H,4) f32: (sum r, sum g, sum b, count) */
+       RTPBR_BUF_IMAGE_PIXELS = 1,   /* T8 image_pixels  (W,H,3) f32 display colour                */
+       RTPBR_BUF_RAY_BUFFER   = 2 }; /* T6 ray_buffer    (W,H) of rtpbr_ray (persistent-ray form)  */
+
+enum { RTPBR_ENV_RGB8 = 0,           /* uint8 (W_e,H_e,3), [x][y], y=0 bottom: what ti.tools.imread gives */
+       RTPBR_ENV_RGB32F = 1 };       /* float32 (W_e,H_e,3) already preprocessed (T9 as is)               */
+
+/* Work counters of the last rtpbr_sample() call (B-bar, S-bar). */
+typedef struct rtpbr_counters {
+    uint64_t samples;       /* pixel-samples (complete-path) or bounce-steps (persistent) */
+    uint64_t raycasts;      /* raycast() calls                                            */
+    uint64_t march_steps;   /* nearest() evaluations inside raycast loops                 */
+    uint64_t hits;          /* surface interactions                                       */
+    uint64_t sky_lookups;   /* environment lookups                                        */
+    uint64_t deposits;      /* image_buffer accumulations                                 */
+} rtpbr_counters;
+
+typedef struct rtpbr_ctx rtpbr_ctx;
+
+/* ------------------------------------------------------------------ entry points */
+
+/* Create a context on HIP device `device`.  Replaces ti.init(arch=...) (src/config.py:5)
+ * plus field allocation (src/fileds.py:7-15). */
+int rtpbr_create(int device, rtpbr_ctx** out);
+int rtpbr_destroy(rtpbr_ctx* ctx);
+const char* rtpbr_last_error(void);
+/* Name of the backend ("hip-gfx950"); lets callers assert which library they loaded. */
+const char* rtpbr_backend(void);
+
+/* Replaces the module constants of src/config.py:7-28.  (Re)allocates the per-pixel
+ * buffers zero-initialised when the resolution changes. */
+int rtpbr_set_config(rtpbr_ctx* ctx, const rtpbr_config* cfg);
+
+/* Replaces the element-wise copy into the `objects` field (src/scene.py:38-41) and
+ * build_scene()/update_all_transform() (src/scene.py:106-113): the world->local
+ * matrices are computed here from `rotation`.  `scale10` != 0 multiplies position and
+ * scale by 10 (cornell_box_v3/sdf.py:16-18). */
+int rtpbr_set_scene(rtpbr_ctx* ctx, const rtpbr_object* objects, int n, int scale10);
+/* Read back the uploaded table (with matrices filled), n entries. */
+int rtpbr_get_scene(rtpbr_ctx* ctx, rtpbr_object* objects, int n);
+
+/* Replaces the 0-d camera fields (src/camera.py:119-129) / the camera kernel arguments
+ * (cornell_box_v3/renderer.py:12-16). */
+int rtpbr_set_camera(rtpbr_ctx* ctx, const rtpbr_camera* cam);
+
+/* Replaces Image(path) + Image.process(exposure, gamma) (src/ibl.py:14-23,32-33).
+ * RGB8 texels are converted as (c/255*exposure)^gamma; RGB32F texels are used as is. */
+int rtpbr_set_env(rtpbr_ctx* ctx, const void* texels, int w, int h, int fmt,
+                  float exposure, float gamma);
+
+/* Tile partition of the frame for multi-GPU rendering: tiles of
+ * tile_w x tile_h pixels are dealt round-robin, tile t belongs to rank t % world.
+ * (0,0,0,1) or world==1 means "the whole frame". */
+int rtpbr_set_tiles(rtpbr_ctx* ctx, int tile_w, int tile_h, int rank, int world);
+
+/* refresh() src/renderer.py:12-22: zero image_buffer, ray_buffer.depth = 0. */
+int rtpbr_refresh(rtpbr_ctx* ctx);
+
+/* The hot path.  complete-path form: `n` samples per owned pixel are traced and
+ * accumulated (the spp loop of cornell_box_v3/renderer.py:31-36).  persistent-ray form:
+ * `n` launches of pathtrace() (src/renderer.py:29-30), each advancing every pixel by
+ * cfg.steps_per_launch bounce-steps.  Asynchronous: returns after enqueue. */
+int rtpbr_sample(rtpbr_ctx* ctx, int n);
+
+/* post_process() src/postprocessor.py:24-43: image_buffer -> image_pixels. */
+int rtpbr_post_process(rtpbr_ctx* ctx);
+
+/* Block until everything enqueued on the context's stream has finished. */
+int rtpbr_sync(rtpbr_ctx* ctx);
+
+/* field.to_numpy() / from_numpy(): copy a whole buffer to/from host memory (blocking). */
+int rtpbr_read_buffer(rtpbr_ctx* ctx, int which, void* dst, size_t nbytes);
+int rtpbr_write_buffer(rtpbr_ctx* ctx, int which, const void* src, size_t nbytes);
+
+/* Multi-GPU gather support.  pack: copy this rank's tiles of image_buffer, tile-major,
+ * into a DEVICE buffer of rtpbr_packed_bytes() bytes (all ranks get the same padded size
+ * so one RCCL gather moves them).  unpack: scatter a packed buffer that belongs to rank
+ * `src_rank` into this context's image_buffer.  Both run on the context's stream. */
+int rtpbr_packed_bytes(rtpbr_ctx* ctx, size_t* nbytes);
+int rtpbr_pack_tiles(rtpbr_ctx* ctx, void* device_dst);
+int rtpbr_unpack_tiles(rtpbr_ctx* ctx, const void* device_src, int src_rank);
+
+/* Measurement hooks (SURVEY.md §5 tracing row, §8(d)). */
+int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking */
+/* Device time (HIP events on the context's stream) of the trace kernel launches and of
+ * all kernels of the last rtpbr_sample() call, in milliseconds (blocking). */
+int rtpbr_last_sample_ms(rtpbr_ctx* ctx, float* trace_ms, float* total_ms, int* launches);
+/* Raw stream handle (hipStream_t) so callers can order their own work after ours. */
+int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
+/* Tuning knobs that do not change results: key in {"staging_bytes","wait_lanes",
+ * "scheduler","waves_per_cu"}.  Returns RTPBR_EINVAL for unknown keys. */
+int rtpbr_set_option(rtpbr_ctx* ctx, const char* key, long long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTPBR_H */

@@ -1,0 +1,188 @@
+"""Renderer: the host-side mirror of the reference's render loop.
+
+reference: src/renderer.py:12-32 — ``refresh()``, ``render(refreshing)`` =
+``[refresh()] ; SAMPLES_PER_FRAME x pathtrace() ; post_process()`` — and the examples'
+kernels ``render(camera_position, camera_lookat, camera_up, moving)``
+(cornell_box_v3/renderer.py:11-42) / ``sample() refresh() render()``
+(bunny_sdf_glass.py:393-432).  Buffers keep the reference's field names and layout:
+``image_buffer`` (W,H,4) f32 = (sum r,g,b, count), ``image_pixels`` (W,H,3) f32,
+``ray_buffer`` (W,H) of Ray; index [i, j] = column from the left, row from the bottom.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .config import FORM, Config
+from .dataclass import Camera, Counters, Ray, SDFObject
+from .scene import Scene
+
+BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS, BUF_RAY_BUFFER = 0, 1, 2
+ENV_RGB8, ENV_RGB32F = 0, 1
+
+
+class Renderer:
+    def __init__(self, scene: Scene, config: Config, camera: Camera = None, device: int = 0, api=None):
+        self.api = api if api is not None else _capi.hip_api()
+        self._ctx = C.c_void_p()
+        self.api.call("create", int(device), C.byref(self._ctx))
+        self.device = device
+        self.samples_per_frame = 1           # SAMPLES_PER_FRAME, src/config.py:9
+        self.set_config(config)
+        self.set_scene(scene)
+        self.set_camera(camera if camera is not None else scene.camera)
+
+    # ------------------------------------------------------------ setup
+    def set_config(self, config: Config):
+        self.config = config.copy()
+        self.api.call("set_config", self._ctx, C.byref(self.config))
+
+    def set_scene(self, scene: Scene):
+        n = len(scene.objects)
+        arr = (SDFObject * n)(*scene.objects)
+        self.api.call("set_scene", self._ctx, arr, n, 1 if scene.scale10 else 0)
+        self.scene = scene
+
+    def get_scene(self):
+        n = len(self.scene.objects)
+        arr = (SDFObject * n)()
+        self.api.call("get_scene", self._ctx, arr, n)
+        return list(arr)
+
+    def set_camera(self, camera: Camera):
+        self.camera = camera
+        self.api.call("set_camera", self._ctx, C.byref(camera))
+
+    def set_env(self, texels: np.ndarray, exposure: float = 1.0, gamma: float = 1.0):
+        """texels: (W_e,H_e,3) uint8 (as ti.tools.imread returns, src/ibl.py:15) or float32."""
+        t = np.ascontiguousarray(texels)
+        if t.ndim != 3 or t.shape[2] != 3:
+            raise ValueError("env texels must have shape (W, H, 3)")
+        if t.dtype == np.uint8:
+            fmt = ENV_RGB8
+        elif t.dtype == np.float32:
+            fmt = ENV_RGB32F
+        else:
+            raise TypeError("env texels must be uint8 or float32")
+        self.api.call("set_env", self._ctx, t.ctypes.data_as(C.c_void_p), t.shape[0], t.shape[1], fmt,
+                      float(exposure), float(gamma))
+
+    def set_tiles(self, tile_w, tile_h, rank, world):
+        self.api.call("set_tiles", self._ctx, tile_w, tile_h, rank, world)
+        self.tiles = (tile_w, tile_h, rank, world)
+
+    def set_option(self, key: str, value: int):
+        self.api.call("set_option", self._ctx, key.encode(), int(value))
+
+    # ------------------------------------------------------------ the reference's calls
+    def refresh(self):
+        """src/renderer.py:12-22."""
+        self.api.call("refresh", self._ctx)
+
+    def sample(self, n: int = 1):
+        """complete-path form: n samples per pixel; persistent-ray form: n pathtrace() launches."""
+        self.api.call("sample", self._ctx, int(n))
+
+    pathtrace = sample
+
+    def post_process(self):
+        """src/postprocessor.py:24-43."""
+        self.api.call("post_process", self._ctx)
+
+    def render(self, refreshing: bool = False, spp: int = None):
+        """src/renderer.py:25-32.  ``spp`` overrides SAMPLES_PER_FRAME for this call."""
+        if refreshing:
+            self.refresh()
+        self.sample(self.samples_per_frame if spp is None else spp)
+        self.post_process()
+
+    def sync(self):
+        self.api.call("sync", self._ctx)
+
+    # ------------------------------------------------------------ buffers (field.to_numpy())
+    def _shape(self, which):
+        W, H = self.config.width, self.config.height
+        return {BUF_IMAGE_BUFFER: ((W, H, 4), np.float32), BUF_IMAGE_PIXELS: ((W, H, 3), np.float32),
+                BUF_RAY_BUFFER: ((W, H, 10), np.float32)}[which]
+
+    def _read(self, which):
+        shape, dt = self._shape(which)
+        out = np.empty(shape, dt)
+        self.api.call("read_buffer", self._ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
+    def _write(self, which, arr):
+        shape, dt = self._shape(which)
+        a = np.ascontiguousarray(arr, dtype=dt)
+        if a.shape != shape:
+            raise ValueError(f"expected shape {shape}, got {a.shape}")
+        self.api.call("write_buffer", self._ctx, which, a.ctypes.data_as(C.c_void_p), a.nbytes)
+
+    @property
+    def image_buffer(self):
+        return self._read(BUF_IMAGE_BUFFER)
+
+    @image_buffer.setter
+    def image_buffer(self, arr):
+        self._write(BUF_IMAGE_BUFFER, arr)
+
+    @property
+    def image_pixels(self):
+        return self._read(BUF_IMAGE_PIXELS)
+
+    @property
+    def ray_buffer(self):
+        """(W,H,10) float32 view of Ray; the last column holds the int32 depth bit pattern."""
+        return self._read(BUF_RAY_BUFFER)
+
+    @ray_buffer.setter
+    def ray_buffer(self, arr):
+        self._write(BUF_RAY_BUFFER, arr)
+
+    def ray_depth(self):
+        return self.ray_buffer[..., 9].view(np.int32)
+
+    # ------------------------------------------------------------ measurement
+    def counters(self) -> Counters:
+        c = Counters()
+        self.api.call("get_counters", self._ctx, C.byref(c))
+        return c
+
+    def last_sample_ms(self):
+        a, b, n = C.c_float(), C.c_float(), C.c_int()
+        self.api.call("last_sample_ms", self._ctx, C.byref(a), C.byref(b), C.byref(n))
+        return a.value, b.value, n.value
+
+    # ------------------------------------------------------------ multi-GPU helpers
+    def packed_bytes(self) -> int:
+        n = C.c_size_t()
+        self.api.call("packed_bytes", self._ctx, C.byref(n))
+        return n.value
+
+    def pack_tiles(self, device_ptr: int):
+        self.api.call("pack_tiles", self._ctx, C.c_void_p(device_ptr))
+
+    def unpack_tiles(self, device_ptr: int, src_rank: int):
+        self.api.call("unpack_tiles", self._ctx, C.c_void_p(device_ptr), int(src_rank))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self.api.call("get_stream", self._ctx, C.byref(s))
+        return s.value or 0
+
+    def close(self):
+        if self._ctx:
+            self.api.call("destroy", self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def display_image(image_pixels: np.ndarray) -> np.ndarray:
+    """(W,H,3) field layout -> (H,W,3) top-down image, the transform ti.tools.imwrite /
+    canvas.set_image apply (src/main.py:55)."""
+    return np.ascontiguousarray(np.swapaxes(image_pixels, 0, 1)[::-1])

@@ -1,0 +1,50 @@
+"""Test helper: drive the CPU oracle (oracle/librt_oracle.so) through the same Python
+Renderer class that drives the HIP library.  Only tests/, smoke() and bench.py's
+cpu_baseline leg may use this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracingpbr_amd._capi import CApi
+from raytracingpbr_amd.renderer import Renderer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "librt_oracle.so")
+_OPTIONAL = ("packed_bytes", "pack_tiles", "unpack_tiles", "last_sample_ms", "get_stream", "set_option")
+
+_api = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def oracle_api():
+    global _api
+    if _api is None:
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        _api = CApi(ORACLE_LIB, "rto_", optional=_OPTIONAL)
+        assert _api.backend() == "cpu-oracle"
+        lib = _api.lib
+        lib.rto_set_threads.argtypes = [C.c_void_p, C.c_int]
+        lib.rto_set_sample_base.argtypes = [C.c_void_p, C.c_uint32]
+        lib.rto_set_bunny_weights.argtypes = [C.c_void_p, C.c_int]
+        w = os.path.join(ROOT, "raytracingpbr_amd", "data", "bunny_weights.npy")
+        if os.path.exists(w):
+            arr = np.ascontiguousarray(np.load(w), dtype=np.float32)
+            lib.rto_set_bunny_weights(arr.ctypes.data_as(C.c_void_p), arr.size)
+    return _api
+
+
+class OracleRenderer(Renderer):
+    def __init__(self, scene, config, camera=None, threads=0):
+        super().__init__(scene, config, camera, device=0, api=oracle_api())
+        if threads:
+            self.api.lib.rto_set_threads(self._ctx, threads)
+
+    def set_sample_base(self, base):
+        self.api.lib.rto_set_sample_base(self._ctx, base)
