@@ -251,6 +251,10 @@ int rtpbr_set_camera(rtpbr_ctx* ctx, const rtpbr_camera* cam);
 int rtpbr_set_env(rtpbr_ctx* ctx, const void* texels, int w, int h, int fmt,
                   float exposure, float gamma);
 
+/* Per-shape data blobs.  Only RTPBR_SHAPE_BUNNY takes one: the 625 weights of the neural
+ * SDF (examples/bunny/bunny_sdf_glass.py:157-201, inline literals in the reference). */
+int rtpbr_set_shape_data(rtpbr_ctx* ctx, int shape, const float* data, int n);
+
 /* Tile partition of the frame for multi-GPU rendering: tiles of
  * tile_w x tile_h pixels are dealt round-robin, tile t belongs to rank t % world.
  * (0,0,0,1) or world==1 means "the whole frame". */

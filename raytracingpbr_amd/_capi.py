@@ -22,7 +22,7 @@ ENTRY_POINTS = [
     "create", "destroy", "last_error", "backend", "set_config", "set_scene", "get_scene",
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",
     "read_buffer", "write_buffer", "packed_bytes", "pack_tiles", "unpack_tiles",
-    "get_counters", "last_sample_ms", "get_stream", "set_option",
+    "get_counters", "last_sample_ms", "get_stream", "set_option", "set_shape_data",
 ]
 
 
@@ -33,7 +33,7 @@ class RtpbrError(RuntimeError):
 
 
 class CApi:
-    def __init__(self, path, prefix="rtpbr_", optional=()):
+    def __init__(self, path, prefix="rtpbr_", optional=("test_math",)):
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} not found — build it first (python -c 'import __graft_entry__ as g; g.build()')")
@@ -64,6 +64,8 @@ class CApi:
             "last_sample_ms": (C.c_int, [p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
             "get_stream": (C.c_int, [p, C.POINTER(p)]),
             "set_option": (C.c_int, [p, C.c_char_p, C.c_longlong]),
+            "set_shape_data": (C.c_int, [p, C.c_int, p, C.c_int]),
+            "test_math": (C.c_int, [p, C.c_int, p, p, p, p, C.c_int]),
         }
         self.fn = {}
         for name, (res, args) in sig.items():

@@ -1,0 +1,46 @@
+"""Build driver: compiles the HIP module for gfx950 in-tree (the .so travels to the GPU box).
+
+  python -m raytracingpbr_amd.build            # build if sources are newer than the .so
+  python -m raytracingpbr_amd.build --force
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "librtpbr_hip.so")
+SOURCES = ["rt_kernels.hip", "rt_capi.hip"]
+HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", os.path.join("..", "..", "include", "rtpbr.h")]
+# -ffp-contract=off: only the fmaf written in rt_math.hpp are fused (bit-reproducible results);
+# no -ffast-math: f32 divide and sqrt stay correctly rounded.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-unused-value"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc()] + FLAGS + list(extra) + SOURCES + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

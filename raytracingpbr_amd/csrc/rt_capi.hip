@@ -1,0 +1,612 @@
+// rt_capi.hip — host side of the C ABI declared in include/rtpbr.h.
+//
+// One rtpbr_ctx owns one HIP stream and every device buffer of one renderer instance (what
+// the Taichi runtime owns in the reference: src/fileds.py:7-15, src/scene.py:38-41,
+// src/ibl.py:16-17).  Each entry point replaces one Taichi kernel launch or field access of
+// the reference; see the header for the line-by-line mapping.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_device.hpp"
+
+namespace rt {
+void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
+void launch_accumulate(const Params& P, hipStream_t st);
+void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
+void launch_refresh(float4* ib, rtpbr_ray* rb, size_t n, hipStream_t st);
+void launch_post_process(const Params& P, hipStream_t st);
+void launch_pack(const Params& P, float4* dst, hipStream_t st);
+void launch_unpack(const Params& P, const float4* src, hipStream_t st);
+void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st);
+int trace_blocks_per_cu(int kind, int n_obj);
+}  // namespace rt
+
+using namespace rt;
+
+static thread_local char g_err[512];
+static int fail(int code, const char* fmt, const char* a = "") {
+    snprintf(g_err, sizeof g_err, fmt, a);
+    return code;
+}
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            return RTPBR_EHIP;                                                         \
+        }                                                                              \
+    } while (0)
+
+struct rtpbr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool have_cfg = false, have_scene = false, have_cam = false;
+    rtpbr_config cfg{};
+    rtpbr_object obj[MAX_OBJ];
+    int n_obj = 0;
+    int kind = KIND_GENERIC;
+    rtpbr_camera cam{};
+    Params P{};
+    // device buffers
+    float4* image_buffer = nullptr;
+    float* image_pixels = nullptr;
+    rtpbr_ray* ray_buffer = nullptr;
+    ObjFull* objfull = nullptr;
+    float4* env = nullptr;
+    float* bunny = nullptr;
+    float4* stage = nullptr;
+    size_t stage_cap = 0;  // bytes
+    unsigned int* work_counter = nullptr;
+    Counters* counters = nullptr;
+    // tiles
+    int tile_w = 0, tile_h = 0, rank = 0, world = 1;
+    // progress
+    uint32_t sample_base = 0;
+    unsigned long long deposits_host = 0;
+    // options
+    long long staging_bytes = 2LL << 30;
+    int wait_lanes = 16;
+    int waves_per_cu = 0;  // 0 = from the occupancy query
+    // timing
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+    hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
+    bool timed = false;
+    int n_cu = 256;
+};
+
+static int set_dev(rtpbr_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return RTPBR_OK;
+}
+
+extern "C" const char* rtpbr_last_error(void) { return g_err; }
+extern "C" const char* rtpbr_backend(void) { return "hip-gfx950"; }
+
+extern "C" int rtpbr_create(int device, rtpbr_ctx** out) {
+    if (!out) return fail(RTPBR_EINVAL, "out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RTPBR_EINVAL, "no such HIP device");
+    rtpbr_ctx* c = new rtpbr_ctx();
+    c->device = device;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->objfull, sizeof(ObjFull) * MAX_OBJ));
+    HIP_TRY(hipMalloc(&c->work_counter, 64));
+    HIP_TRY(hipMalloc(&c->counters, sizeof(Counters)));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipEventCreate(&c->ev_total0));
+    HIP_TRY(hipEventCreate(&c->ev_total1));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount;
+    *out = c;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
+    if (!c) return RTPBR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->image_buffer);
+    (void)hipFree(c->image_pixels);
+    (void)hipFree(c->ray_buffer);
+    (void)hipFree(c->objfull);
+    (void)hipFree(c->env);
+    (void)hipFree(c->bunny);
+    (void)hipFree(c->stage);
+    (void)hipFree(c->work_counter);
+    (void)hipFree(c->counters);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->ev_total0);
+    (void)hipEventDestroy(c->ev_total1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RTPBR_OK;
+}
+
+static void update_tiles(rtpbr_ctx* c) {
+    Params& P = c->P;
+    const int W = c->cfg.width, H = c->cfg.height;
+    int tw = c->tile_w, th = c->tile_h;
+    if (c->world <= 1 || tw <= 0 || th <= 0) {
+        if (tw <= 0 || th <= 0) {
+            tw = W;
+            th = H;
+        }
+    }
+    P.tile_w = tw;
+    P.tile_h = th;
+    P.ntx = (W + tw - 1) / tw;
+    P.nty = (H + th - 1) / th;
+    P.rank = c->rank;
+    P.world = c->world;
+    int ntiles = P.ntx * P.nty;
+    P.n_local_tiles = (ntiles + c->world - 1) / c->world;
+    P.np = P.n_local_tiles * tw * th;
+}
+
+extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
+    if (!c || !cfg) return fail(RTPBR_EINVAL, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 65535 || cfg->height > 65535)
+        return fail(RTPBR_EINVAL, "resolution out of range (1..65535)");
+    if (cfg->max_raymarch <= 0 || cfg->max_raytrace <= 0) return fail(RTPBR_EINVAL, "max_raymarch/max_raytrace must be > 0");
+    if (int r = set_dev(c)) return r;
+    bool realloc_buf = !c->have_cfg || c->cfg.width != cfg->width || c->cfg.height != cfg->height;
+    c->cfg = *cfg;
+    c->P.cfg = *cfg;
+    c->have_cfg = true;
+    if (realloc_buf) {
+        size_t n = (size_t)cfg->width * cfg->height;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->image_buffer);
+        (void)hipFree(c->image_pixels);
+        (void)hipFree(c->ray_buffer);
+        c->image_buffer = nullptr;
+        c->image_pixels = nullptr;
+        c->ray_buffer = nullptr;
+        HIP_TRY(hipMalloc(&c->image_buffer, n * sizeof(float4)));
+        HIP_TRY(hipMalloc(&c->image_pixels, n * 3 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->ray_buffer, n * sizeof(rtpbr_ray)));
+        HIP_TRY(hipMemsetAsync(c->image_buffer, 0, n * sizeof(float4), c->stream));
+        HIP_TRY(hipMemsetAsync(c->image_pixels, 0, n * 3 * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->ray_buffer, 0, n * sizeof(rtpbr_ray), c->stream));
+    }
+    // bunny animation uniform: t = pi*frame/120 (bunny_sdf_glass.py:214)
+    float t = PI * (float)cfg->frame / 120.0f;
+    sincos_(t, &c->P.anim_s, &c->P.anim_c);
+    update_tiles(c);
+    return RTPBR_OK;
+}
+
+// Euler -> matrix, src/util.py:36-42: M = Rz @ Ry @ Rx (row major)
+static void m3_mul(const float* a, const float* b, float* o) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            o[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+}
+static void rotate(const float* rad, float* m) {
+    float sx = (float)sin((double)rad[0]), cx = (float)cos((double)rad[0]);
+    float sy = (float)sin((double)rad[1]), cy = (float)cos((double)rad[1]);
+    float sz = (float)sin((double)rad[2]), cz = (float)cos((double)rad[2]);
+    float rz[9] = {cz, sz, 0, -sz, cz, 0, 0, 0, 1};
+    float ry[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
+    float rx[9] = {1, 0, 0, 0, cx, sx, 0, -sx, cx};
+    float t[9];
+    m3_mul(rz, ry, t);
+    m3_mul(t, rx, m);
+}
+
+extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, int scale10) {
+    if (!c || !objs) return fail(RTPBR_EINVAL, "null argument");
+    if (n <= 0 || n > MAX_OBJ) return fail(RTPBR_EINVAL, "object count must be 1..32");
+    if (int r = set_dev(c)) return r;
+    ObjFull full[MAX_OBJ];
+    memset(full, 0, sizeof full);
+    bool all_box = true;
+    for (int i = 0; i < n; i++) {
+        c->obj[i] = objs[i];
+        rtpbr_transform& t = c->obj[i].transform;
+        if (scale10)
+            for (int k = 0; k < 3; k++) {
+                t.position[k] *= 10.0f;
+                t.scale[k] *= 10.0f;
+            }
+        float rad[3] = {t.rotation[0] * DEG2RAD, t.rotation[1] * DEG2RAD, t.rotation[2] * DEG2RAD};
+        rotate(rad, t.matrix);
+        ObjM& m = c->P.objm[i];
+        m.px = t.position[0]; m.py = t.position[1]; m.pz = t.position[2];
+        memcpy(m.m, t.matrix, sizeof m.m);
+        m.sx = t.scale[0]; m.sy = t.scale[1]; m.sz = t.scale[2];
+        m.type = c->obj[i].type;
+        ObjFull& f = full[i];
+        memcpy(&f, &m, sizeof m);
+        const rtpbr_material& mt = c->obj[i].material;
+        memcpy(f.albedo, mt.albedo, 12);
+        memcpy(f.emission, mt.emission, 12);
+        f.roughness = mt.roughness; f.metallic = mt.metallic; f.transmission = mt.transmission; f.ior = mt.ior;
+        if (m.type != RTPBR_SHAPE_BOX) all_box = false;
+        if (m.type < RTPBR_SHAPE_NONE || m.type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
+    }
+    c->n_obj = n;
+    c->P.n_obj = n;
+    c->kind = all_box ? KIND_BOXES : KIND_GENERIC;
+    HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
+    c->have_scene = true;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_get_scene(rtpbr_ctx* c, rtpbr_object* objs, int n) {
+    if (!c || !objs || n < 0 || n > c->n_obj) return fail(RTPBR_EINVAL, "bad get_scene arguments");
+    memcpy(objs, c->obj, (size_t)n * sizeof *objs);
+    return RTPBR_OK;
+}
+
+// thin-lens frame, src/camera.py:11-31 (same operation order as the oracle's camera_frame)
+extern "C" int rtpbr_set_camera(rtpbr_ctx* c, const rtpbr_camera* cam) {
+    if (!c || !cam) return fail(RTPBR_EINVAL, "null argument");
+    c->cam = *cam;
+    vec3 lf = mk(cam->lookfrom[0], cam->lookfrom[1], cam->lookfrom[2]);
+    vec3 la = mk(cam->lookat[0], cam->lookat[1], cam->lookat[2]);
+    vec3 up = mk(cam->vup[0], cam->vup[1], cam->vup[2]);
+    float theta = cam->vfov * DEG2RAD;
+    float hh = tanf(theta * 0.5f);
+    float hw = cam->aspect * hh;
+    vec3 z = normalize(lf - la);
+    vec3 x = normalize(cross(up, z));
+    vec3 y = cross(z, x);
+    vec3 hwfx = x * (hw * cam->focus);
+    vec3 hhfy = y * (hh * cam->focus);
+    vec3 llc = ((lf - hwfx) - hhfy) - z * cam->focus;
+    vec3 hor = hwfx * 2.0f, ver = hhfy * 2.0f;
+    CamFrame& f = c->P.cam;
+    f.lf[0] = lf.x; f.lf[1] = lf.y; f.lf[2] = lf.z;
+    f.x[0] = x.x; f.x[1] = x.y; f.x[2] = x.z;
+    f.y[0] = y.x; f.y[1] = y.y; f.y[2] = y.z;
+    f.llc[0] = llc.x; f.llc[1] = llc.y; f.llc[2] = llc.z;
+    f.hor[0] = hor.x; f.hor[1] = hor.y; f.hor[2] = hor.z;
+    f.ver[0] = ver.x; f.ver[1] = ver.y; f.ver[2] = ver.z;
+    f.lens_radius = cam->aperture * 0.5f;
+    c->have_cam = true;
+    return RTPBR_OK;
+}
+
+// Image(path) + Image.process(exposure, gamma): src/ibl.py:14-23, postprocessor.adjust :17-21
+extern "C" int rtpbr_set_env(rtpbr_ctx* c, const void* texels, int w, int h, int fmt, float exposure, float gamma) {
+    if (!c || !texels) return fail(RTPBR_EINVAL, "null argument");
+    if (w <= 0 || h <= 0) return fail(RTPBR_EINVAL, "bad env size");
+    if (fmt != RTPBR_ENV_RGB8 && fmt != RTPBR_ENV_RGB32F) return fail(RTPBR_EINVAL, "bad env format");
+    if (int r = set_dev(c)) return r;
+    size_t n = (size_t)w * h;
+    std::vector<float4> host(n);
+    if (fmt == RTPBR_ENV_RGB8) {
+        const uint8_t* s = (const uint8_t*)texels;
+        float lut[256];
+        for (int i = 0; i < 256; i++) lut[i] = powf(((float)i / 255.0f) * exposure, gamma);
+        for (size_t i = 0; i < n; i++) host[i] = make_float4(lut[s[i * 3]], lut[s[i * 3 + 1]], lut[s[i * 3 + 2]], 0.0f);
+    } else {
+        const float* s = (const float*)texels;
+        for (size_t i = 0; i < n; i++) host[i] = make_float4(s[i * 3], s[i * 3 + 1], s[i * 3 + 2], 0.0f);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->env);
+    c->env = nullptr;
+    HIP_TRY(hipMalloc(&c->env, n * sizeof(float4)));
+    HIP_TRY(hipMemcpy(c->env, host.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    c->P.env = c->env;
+    c->P.env_w = w;
+    c->P.env_h = h;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_set_shape_data(rtpbr_ctx* c, int shape, const float* data, int n) {
+    if (!c || !data) return fail(RTPBR_EINVAL, "null argument");
+    if (shape != RTPBR_SHAPE_BUNNY || n != 625) return fail(RTPBR_EINVAL, "only the bunny MLP (625 weights) takes shape data");
+    if (int r = set_dev(c)) return r;
+    if (!c->bunny) HIP_TRY(hipMalloc(&c->bunny, 625 * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->bunny, data, 625 * sizeof(float), hipMemcpyHostToDevice));
+    c->P.bunny = c->bunny;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (world < 1 || rank < 0 || rank >= world) return fail(RTPBR_EINVAL, "bad rank/world");
+    if (world > 1 && (tw <= 0 || th <= 0)) return fail(RTPBR_EINVAL, "tile size must be > 0 when world > 1");
+    c->tile_w = tw;
+    c->tile_h = th;
+    c->rank = rank;
+    c->world = world;
+    if (c->have_cfg) update_tiles(c);
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
+    if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
+    if (int r = set_dev(c)) return r;
+    size_t n = (size_t)c->cfg.width * c->cfg.height;
+    launch_refresh(c->image_buffer, c->ray_buffer, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    return RTPBR_OK;
+}
+
+static hipEvent_t next_event(rtpbr_ctx* c) {
+    if (c->ev_used == (int)c->ev.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->ev.push_back(e);
+    }
+    return c->ev[c->ev_used++];
+}
+
+static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
+    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj);
+    if (per_cu <= 0) per_cu = 2;
+    if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
+    long long grid = (long long)per_cu * c->n_cu;
+    long long need = ((long long)total_items + 255) / 256;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    return (int)grid;
+}
+
+extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
+    if (n < 0) return fail(RTPBR_EINVAL, "n must be >= 0");
+    if (int r = set_dev(c)) return r;
+    Params& P = c->P;
+    P.cfg = c->cfg;
+    P.cam.inv_w = 1.0f / (float)c->cfg.width;
+    P.cam.inv_h = 1.0f / (float)c->cfg.height;
+    P.image_buffer = c->image_buffer;
+    P.image_pixels = c->image_pixels;
+    P.ray_buffer = c->ray_buffer;
+    P.objfull = c->objfull;
+    P.work_counter = c->work_counter;
+    P.counters = c->counters;
+    P.wait_lanes = c->wait_lanes;
+    for (int i = 0; i < c->n_obj; i++)
+        if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
+    if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    c->deposits_host = 0;
+    c->ev_used = 0;
+    c->timed = true;
+    HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
+    if (c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY) {
+        // n launches of pathtrace() (src/renderer.py:29-30)
+        for (int i = 0; i < n; i++) {
+            P.sample_base = c->sample_base;
+            hipEvent_t a = next_event(c), b = next_event(c);
+            HIP_TRY(hipEventRecord(a, c->stream));
+            launch_persistent(P, c->kind, c->cfg.steps_per_launch, c->stream);
+            HIP_TRY(hipEventRecord(b, c->stream));
+            c->sample_base += (uint32_t)c->cfg.steps_per_launch;
+        }
+    } else {
+        int left = n;
+        while (left > 0) {
+            long long per_spp = (long long)P.np * (long long)sizeof(float4);
+            long long kmax = c->staging_bytes / per_spp;
+            if (kmax < 1) kmax = 1;
+            // keep total_items within 32 bits
+            long long k32 = 0xFFFFFFFFLL / (long long)P.np - 1;
+            if (kmax > k32) kmax = k32;
+            int K = (int)(left < kmax ? left : kmax);
+            size_t need = (size_t)per_spp * (size_t)K;
+            if (need > c->stage_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                (void)hipFree(c->stage);
+                c->stage = nullptr;
+                c->stage_cap = 0;
+                HIP_TRY(hipMalloc(&c->stage, need));
+                c->stage_cap = need;
+            }
+            P.stage = c->stage;
+            P.K = K;
+            P.sample_base = c->sample_base;
+            P.total_items = (uint32_t)((long long)P.np * K);
+            int grid = trace_grid(c, P.total_items);
+            long long waves = (long long)grid * 4;
+            long long chunk = (long long)P.total_items / (waves * 16);
+            if (chunk < 64) chunk = 64;
+            if (chunk > 4096) chunk = 4096;
+            P.chunk = (uint32_t)chunk;
+            HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
+            hipEvent_t a = next_event(c), b = next_event(c);
+            HIP_TRY(hipEventRecord(a, c->stream));
+            launch_trace(P, c->kind, grid, c->stream);
+            HIP_TRY(hipEventRecord(b, c->stream));
+            launch_accumulate(P, c->stream);
+            c->sample_base += (uint32_t)K;
+            left -= K;
+        }
+        // deposits = valid owned pixels * n
+        unsigned long long valid = 0;
+        for (int tl = 0; tl < P.n_local_tiles; tl++) {
+            int tid = P.rank + tl * P.world;
+            if (tid >= P.ntx * P.nty) continue;
+            int ty = tid / P.ntx, tx = tid % P.ntx;
+            int w = c->cfg.width - tx * P.tile_w, h = c->cfg.height - ty * P.tile_h;
+            if (w > P.tile_w) w = P.tile_w;
+            if (h > P.tile_h) h = P.tile_h;
+            valid += (unsigned long long)w * h;
+        }
+        c->deposits_host = valid * (unsigned long long)n;
+    }
+    HIP_TRY(hipEventRecord(c->ev_total1, c->stream));
+    HIP_TRY(hipGetLastError());
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_post_process(rtpbr_ctx* c) {
+    if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
+    if (int r = set_dev(c)) return r;
+    c->P.cfg = c->cfg;
+    c->P.image_buffer = c->image_buffer;
+    c->P.image_pixels = c->image_pixels;
+    launch_post_process(c->P, c->stream);
+    HIP_TRY(hipGetLastError());
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_sync(rtpbr_ctx* c) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTPBR_OK;
+}
+
+static int buf_ptr(rtpbr_ctx* c, int which, void** p, size_t* n) {
+    if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
+    size_t np = (size_t)c->cfg.width * c->cfg.height;
+    switch (which) {
+        case RTPBR_BUF_IMAGE_BUFFER: *p = c->image_buffer; *n = np * 16; return 0;
+        case RTPBR_BUF_IMAGE_PIXELS: *p = c->image_pixels; *n = np * 12; return 0;
+        case RTPBR_BUF_RAY_BUFFER: *p = c->ray_buffer; *n = np * sizeof(rtpbr_ray); return 0;
+    }
+    return fail(RTPBR_EINVAL, "unknown buffer id");
+}
+
+extern "C" int rtpbr_read_buffer(rtpbr_ctx* c, int which, void* dst, size_t nbytes) {
+    void* p;
+    size_t n;
+    if (int r = buf_ptr(c, which, &p, &n)) return r;
+    if (!dst || nbytes != n) return fail(RTPBR_EINVAL, "destination size does not match the buffer");
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_write_buffer(rtpbr_ctx* c, int which, const void* src, size_t nbytes) {
+    void* p;
+    size_t n;
+    if (int r = buf_ptr(c, which, &p, &n)) return r;
+    if (!src || nbytes != n) return fail(RTPBR_EINVAL, "source size does not match the buffer");
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_packed_bytes(rtpbr_ctx* c, size_t* nbytes) {
+    if (!c || !nbytes || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
+    *nbytes = (size_t)c->P.np * sizeof(float4);
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_pack_tiles(rtpbr_ctx* c, void* device_dst) {
+    if (!c || !device_dst || !c->have_cfg) return fail(RTPBR_EINVAL, "bad pack_tiles arguments");
+    if (int r = set_dev(c)) return r;
+    c->P.cfg = c->cfg;
+    c->P.image_buffer = c->image_buffer;
+    launch_pack(c->P, (float4*)device_dst, c->stream);
+    HIP_TRY(hipGetLastError());
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_unpack_tiles(rtpbr_ctx* c, const void* device_src, int src_rank) {
+    if (!c || !device_src || !c->have_cfg) return fail(RTPBR_EINVAL, "bad unpack_tiles arguments");
+    if (src_rank < 0 || src_rank >= c->world) return fail(RTPBR_EINVAL, "src_rank out of range");
+    if (int r = set_dev(c)) return r;
+    Params P = c->P;
+    P.cfg = c->cfg;
+    P.image_buffer = c->image_buffer;
+    P.rank = src_rank;
+    launch_unpack(P, (const float4*)device_src, c->stream);
+    HIP_TRY(hipGetLastError());
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
+    if (!c || !out) return fail(RTPBR_EINVAL, "null argument");
+    if (int r = set_dev(c)) return r;
+    Counters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out->samples = h.samples;
+    out->raycasts = h.raycasts;
+    out->march_steps = h.march_steps;
+    out->hits = h.hits;
+    out->sky_lookups = h.sky_lookups;
+    out->deposits = h.deposits + c->deposits_host;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_last_sample_ms(rtpbr_ctx* c, float* trace_ms, float* total_ms, int* launches) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (!c->timed) return fail(RTPBR_ESTATE, "no rtpbr_sample() call to time yet");
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float tr = 0.0f;
+    for (int i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        tr += ms;
+    }
+    float tot = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&tot, c->ev_total0, c->ev_total1));
+    if (trace_ms) *trace_ms = tr;
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = c->ev_used / 2;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_get_stream(rtpbr_ctx* c, void** stream) {
+    if (!c || !stream) return fail(RTPBR_EINVAL, "null argument");
+    *stream = (void*)c->stream;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) {
+    if (!c || !key) return fail(RTPBR_EINVAL, "null argument");
+    if (!strcmp(key, "staging_bytes")) {
+        if (value < (1 << 20)) return fail(RTPBR_EINVAL, "staging_bytes must be >= 1 MiB");
+        c->staging_bytes = value;
+    } else if (!strcmp(key, "wait_lanes")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "wait_lanes must be 1..64");
+        c->wait_lanes = (int)value;
+    } else if (!strcmp(key, "waves_per_cu")) {
+        if (value < 0 || value > 32) return fail(RTPBR_EINVAL, "waves_per_cu must be 0..32");
+        c->waves_per_cu = (int)value;
+    } else if (!strcmp(key, "sample_base")) {
+        c->sample_base = (uint32_t)value;
+    } else {
+        return fail(RTPBR_EINVAL, "unknown option %s", key);
+    }
+    return RTPBR_OK;
+}
+
+// test hook: exact math functions evaluated on the device (not part of the drop-in surface)
+extern "C" int rtpbr_test_math(rtpbr_ctx* c, int op, const float* a, const float* b, float* out, float* out2, int n) {
+    if (!c || !a || !out || n <= 0) return fail(RTPBR_EINVAL, "bad test_math arguments");
+    if (int r = set_dev(c)) return r;
+    float *da = nullptr, *db = nullptr, *dout = nullptr, *dout2 = nullptr;
+    size_t nb = (size_t)n * sizeof(float);
+    HIP_TRY(hipMalloc(&da, nb));
+    HIP_TRY(hipMalloc(&dout, nb));
+    HIP_TRY(hipMalloc(&dout2, nb));
+    HIP_TRY(hipMemcpy(da, a, nb, hipMemcpyHostToDevice));
+    if (b) {
+        HIP_TRY(hipMalloc(&db, nb));
+        HIP_TRY(hipMemcpy(db, b, nb, hipMemcpyHostToDevice));
+    }
+    launch_math_probe(op, da, db, dout, dout2, n, c->stream);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost));
+    if (out2) HIP_TRY(hipMemcpy(out2, dout2, nb, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    (void)hipFree(dout2);
+    return RTPBR_OK;
+}

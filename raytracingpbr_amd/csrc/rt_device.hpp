@@ -1,0 +1,435 @@
+// rt_device.hpp — device functions of the sample path (gfx950, wave64).
+//
+// Stage functions of SURVEY.md §8(a): F5 camera ray, F7/F21 sphere tracing step, F8 nearest,
+// F9/F10 transform + SDF primitives, F11 normal, F12/F22 surface interaction, F13 sky,
+// F15 sampling helpers, F19 tone map, F23 neural bunny SDF.  Each cites the reference lines
+// whose behaviour it reproduces; arithmetic follows rt_math.hpp (exact ops, fixed order).
+#pragma once
+#include "rt_types.hpp"
+
+namespace rt {
+
+enum { KIND_GENERIC = 0, KIND_BOXES = 1 };
+
+// ---------------------------------------------------------------- F23 bunny MLP
+// examples/bunny/bunny_sdf_glass.py:149-203; weight layout: see tools/extract_bunny_weights.py
+RT_D float sd_bunny(const float* __restrict__ w, vec3 p) {
+    float len = length(p);
+    if (len > 1.0f || w == nullptr) return len - 0.8f;
+    float f0[16], f1[16], f2[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float* b = w + k * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float a = p.y * b[j] + p.z * b[4 + j] - p.x * b[8 + j] + b[12 + j];
+            f0[k * 4 + j] = sin_(a);
+        }
+    }
+#pragma unroll
+    for (int layer = 0; layer < 2; layer++) {
+        const float* lw = w + 64 + layer * 272;
+        const float* src = layer == 0 ? f0 : f1;
+        float* dst = layer == 0 ? f1 : f2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float* bw = lw + k * 68;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const float* M = bw + m * 16;
+                    const float* v = src + m * 4;
+                    float t = v[0] * M[0 * 4 + j] + v[1] * M[1 * 4 + j] + v[2] * M[2 * 4 + j] + v[3] * M[3 * 4 + j];
+                    acc = (m == 0) ? t : acc + t;
+                }
+                acc = acc + bw[64 + j];
+                float sn = sin_(acc);
+                if (layer == 1) sn = sn / 1.4f;
+                dst[k * 4 + j] = sn + src[k * 4 + j];
+            }
+        }
+    }
+    const float* ow = w + 64 + 544;
+    float sd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float* v = f2 + k * 4;
+        float t = v[0] * ow[k * 4 + 0] + v[1] * ow[k * 4 + 1] + v[2] * ow[k * 4 + 2] + v[3] * ow[k * 4 + 3];
+        sd = (k == 0) ? t : sd + t;
+    }
+    return sd + ow[16];
+}
+
+// ---------------------------------------------------------------- F10 SDF primitives
+// src/sdf.py:21-51 (l = local position, s = transform.scale); box rounding rho per variant
+RT_D float sd_box(vec3 l, float sx, float sy, float sz, float rho) {
+    float qx = fabs_(l.x) - sx, qy = fabs_(l.y) - sy, qz = fabs_(l.z) - sz;
+    vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
+    return (length(m) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+}
+
+template <int KIND>
+RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, float sz) {
+    if (KIND == KIND_BOXES) return sd_box(l, sx, sy, sz, P.cfg.box_round);
+    switch (type) {
+        case RTPBR_SHAPE_SPHERE:
+            return length(l) - sx;
+        case RTPBR_SHAPE_BOX:
+            return sd_box(l, sx, sy, sz, P.cfg.box_round);
+        case RTPBR_SHAPE_CYLINDER: {
+            float r = sqrt_(fma_(l.z, l.z, l.x * l.x));
+            float dx = fabs_(r) - sx, dy = fabs_(l.y) - sy;
+            float mx = fmax_(dx, 0.0f), my = fmax_(dy, 0.0f);
+            return fmin_(fmax_(dx, dy), 0.0f) + sqrt_(fma_(my, my, mx * mx));
+        }
+        case RTPBR_SHAPE_CONE: {
+            float q = sqrt_(fma_(l.z, l.z, l.x * l.x));
+            return fmax_(fma_(sz, l.y, sx * q), -sy - l.y);
+        }
+        case RTPBR_SHAPE_PLANE:
+            return l.y - sy;
+        case RTPBR_SHAPE_BUNNY:
+            return sd_bunny(P.bunny, l);
+        default:
+            return P.cfg.max_dis;
+    }
+}
+
+// F9 world -> local (src/sdf.py:64-68) + the bunny's per-frame animation (bunny_sdf_glass.py:213-217)
+template <int KIND, typename OBJ>
+RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p) {
+    vec3 d = p - mk(o.px, o.py, o.pz);
+    vec3 l = mulv(o.m, d);
+    if (KIND != KIND_BOXES && o.type == RTPBR_SHAPE_BUNNY) {
+        float st = P.anim_s, ct = P.anim_c;
+        vec3 r = mk(fma_(st, l.y, ct * l.x), fma_(ct, l.y, -st * l.x), l.z);
+        r.z = r.z + 0.1f * st;
+        l = r;
+    }
+    return l;
+}
+
+template <int KIND, typename OBJ>
+RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p) {
+    return sdf_local<KIND>(P, o.type, to_local<KIND>(P, o, p), o.sx, o.sy, o.sz);
+}
+
+// ---------------------------------------------------------------- F8 nearest
+// min_i |sdf_i|, ties to the lowest index (cornell_box_v3/pathtracer.py:41-49; src/scene.py:44-56).
+// The object table is read from the kernarg segment at wave-uniform indices -> scalar loads.
+template <int KIND, int NOBJ>
+RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
+    const int n = NOBJ > 0 ? NOBJ : P.n_obj;
+    int start;
+    idx = 0;
+    if (P.cfg.nearest_init) {
+        best = P.cfg.max_dis;
+        start = 0;
+    } else {
+        best = fabs_(signed_distance<KIND>(P, P.objm[0], p));
+        start = 1;
+    }
+    if (NOBJ > 0) {
+#pragma unroll
+        for (int i = 0; i < NOBJ; i++) {
+            if (i >= start) {
+                float d = fabs_(signed_distance<KIND>(P, P.objm[i], p));
+                bool lt = d < best;
+                best = lt ? d : best;
+                idx = lt ? i : idx;
+            }
+        }
+    } else {
+        for (int i = start; i < n; i++) {
+            float d = fabs_(signed_distance<KIND>(P, P.objm[i], p));
+            bool lt = d < best;
+            best = lt ? d : best;
+            idx = lt ? i : idx;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-lane path state
+enum { ST_IDLE = 0, ST_MARCH = 1, ST_HIT = 2, ST_MISS = 3, ST_EXHAUSTED = 4 };
+
+struct Lane {
+    vec3 o, d, col;
+    float t, w, s, dist;  // sphere-tracing state (raycast locals of the reference)
+    float t_eval;         // t of the last evaluated position (record.position = o + t_eval*d)
+    int idx;              // nearest object at the last evaluation (record.object)
+    int steps_left;
+    int bounce;           // i of "for i in range(MAX_RAYTRACE)"
+    uint32_t key, cnt;    // RNG stream
+    uint32_t item;        // work item = q*K + k
+    int state;
+    uint32_t n_steps, n_raycasts, n_hits, n_sky;  // work counters
+};
+
+// start of raycast(): cornell_box_v3/pathtracer.py:54-56 / cornell_box_v2.py:187
+RT_D void march_init(const Params& P, Lane& L) {
+    L.t = P.cfg.min_dis;
+    L.w = P.cfg.omega0;
+    L.s = 0.0f;
+    L.dist = 0.0f;
+    L.steps_left = P.cfg.max_raymarch;
+    L.state = ST_MARCH;
+    L.n_raycasts++;
+}
+
+// One iteration of the examples' raycast loop.  plain: cornell_box_v2.py:186-196;
+// relaxed: cornell_box_v3/pathtracer.py:57-76, tokyo_ibl.py:249-263, bunny_sdf_glass.py:252-265.
+template <int KIND, int NOBJ>
+RT_D void march_step(const Params& P, Lane& L) {
+    vec3 pos = fma3(L.t, L.d, L.o);
+    L.t_eval = L.t;
+    int idx;
+    float dist;
+    nearest<KIND, NOBJ>(P, pos, idx, dist);
+    L.idx = idx;
+    L.n_steps++;
+    L.steps_left--;
+    bool hit, done;
+    if (P.cfg.march_kind == RTPBR_MARCH_PLAIN) {
+        L.t += dist;
+        hit = dist < P.cfg.hit_eps;
+        done = hit || L.t > P.cfg.max_dis;
+    } else {
+        float ld = L.dist;
+        L.dist = dist;
+        bool fb = (!P.cfg.omega_guard || L.w > 1.0f) && (ld + dist < L.s);
+        // fallback branch: s -= w*s; t += s; w = a + b*w; continue
+        float s_fb = L.s - L.w * L.s;
+        float w_fb = P.cfg.omega_fb_a + P.cfg.omega_fb_b * L.w;
+        // normal branch
+        float err = dist / L.t;
+        float s_nm = L.w * dist;
+        float s_new = fb ? s_fb : s_nm;
+        L.s = s_new;
+        L.t += s_new;
+        L.w = fb ? w_fb : L.w;
+        hit = !fb && (err < P.cfg.hit_eps);
+        done = !fb && (hit || L.t > P.cfg.max_dis);
+    }
+    done = done || (L.steps_left == 0);
+    if (done) L.state = hit ? ST_HIT : ST_MISS;
+}
+
+// ---------------------------------------------------------------- F11 normal
+// world: cornell_box_v3/sdf.py:26-31; local: src/sdf.py:77-87 + src/scene.py:87-96
+template <int KIND>
+RT_D vec3 calc_normal(const Params& P, const ObjFull& o, vec3 p) {
+    float h = P.cfg.normal_h;
+    if (P.cfg.normal_space == RTPBR_NORMAL_WORLD) {
+        vec3 e0 = mk(h, -h, -h), e1 = mk(-h, -h, h), e2 = mk(-h, h, -h), e3 = mk(h, h, h);
+        float d0 = signed_distance<KIND>(P, o, p + e0);
+        float d1 = signed_distance<KIND>(P, o, p + e1);
+        float d2 = signed_distance<KIND>(P, o, p + e2);
+        float d3 = signed_distance<KIND>(P, o, p + e3);
+        vec3 n = ((e0 * d0 + e1 * d1) + e2 * d2) + e3 * d3;
+        return normalize(n);
+    } else {
+        vec3 q = to_local<KIND>(P, o, p);
+        vec3 e0 = mk(1, -1, -1), e1 = mk(-1, -1, 1), e2 = mk(-1, 1, -1), e3 = mk(1, 1, 1);
+        float d0 = sdf_local<KIND>(P, o.type, q + e0 * h, o.sx, o.sy, o.sz);
+        float d1 = sdf_local<KIND>(P, o.type, q + e1 * h, o.sx, o.sy, o.sz);
+        float d2 = sdf_local<KIND>(P, o.type, q + e2 * h, o.sx, o.sy, o.sz);
+        float d3 = sdf_local<KIND>(P, o.type, q + e3 * h, o.sx, o.sy, o.sz);
+        vec3 n = mk(0, 0, 0);
+        n = n + e0 * d0;
+        n = n + e1 * d1;
+        n = n + e2 * d2;
+        n = n + e3 * d3;
+        return normalize(n);
+    }
+}
+
+RT_D float brightness(vec3 c) { return dot(c, mk(0.299f, 0.587f, 0.114f)); }  // src/util.py:31-33
+
+// F15: src/util.py:21-28 random_in_unit_sphere + src/pbr.py:16-19 hemispheric_sampling
+RT_D vec3 hemispheric_sampling(vec3 n, uint32_t key, uint32_t& cnt) {
+    float a = rng_next(key, cnt), b = rng_next(key, cnt);
+    float z = 2.0f * a - 1.0f;
+    float ang = b * 2.0f * PI;
+    float sn, cs;
+    sincos_(ang, &sn, &cs);
+    float sq = sqrt_(1.0f - z * z);
+    vec3 u = mk(sq * sn, sq * cs, z);
+    return normalize(n + u);
+}
+
+// ---------------------------------------------------------------- F12/F22 surface interaction
+// src/pbr.py:22-62; cornell_box_v3/pbr.py:30-66; cornell_box_shortest.py:91-94.
+// `origin` is the ray origin (src form: already marched), `pos` the hit position.
+template <int KIND>
+RT_D void surface_interaction(const Params& P, const ObjFull& o, vec3 pos, vec3& origin, vec3& dir, vec3& col,
+                              uint32_t key, uint32_t& cnt) {
+    const rtpbr_config& g = P.cfg;
+    vec3 albedo = mk(o.albedo[0], o.albedo[1], o.albedo[2]);
+    vec3 n = calc_normal<KIND>(P, o, pos);
+    if (g.surface_kind == RTPBR_SURFACE_DIFFUSE) {
+        dir = hemispheric_sampling(n, key, cnt);
+        col = col * albedo;
+        origin = pos;
+        return;
+    }
+    vec3 I = dir;
+    bool outer = dot(I, n) < 0.0f;
+    if (!outer) n = -n;
+    vec3 hemi = hemispheric_sampling(n, key, cnt);
+    float alpha = o.roughness * o.roughness;
+    vec3 N = normalize(mix(n, hemi, alpha));
+    float NoI = dot(N, I);
+    float eta = outer ? g.env_ior / o.ior : o.ior / g.env_ior;
+    float k = 1.0f - eta * eta * (1.0f - NoI * NoI);
+    float F0;
+    if (g.fresnel_kind == RTPBR_FRESNEL_C2) {
+        F0 = (eta - 1.0f) / (eta + 1.0f);
+        F0 = F0 * (2.0f * F0);
+    } else {
+        F0 = 2.0f * (eta - 1.0f) / (eta + 1.0f);
+        F0 = F0 * F0;
+    }
+    float x1 = fabs_(1.0f + NoI), x2 = x1 * x1, x5 = x2 * x2 * x1;
+    float F = mix(x5, 1.0f, F0);
+    if (g.fresnel_roughness_mix) F = mix(F, F0, o.roughness);
+    vec3 D;
+    float c1 = rng_next(key, cnt);
+    if (c1 < F + o.metallic || k < 0.0f) {
+        float tn = 2.0f * NoI;
+        D = mk(I.x - tn * N.x, I.y - tn * N.y, I.z - tn * N.z);
+        if (g.below_horizon == RTPBR_HORIZON_KILL) {
+            float keep = dot(D, n) > 0.0f ? 1.0f : 0.0f;
+            col = col * keep;
+        } else if (dot(D, n) < 0.0f) {
+            D = -D;
+        }
+    } else {
+        float c2 = rng_next(key, cnt);
+        if (c2 < o.transmission) {
+            float f = sqrt_(k) + eta * NoI;
+            D = mk(eta * I.x - f * N.x, eta * I.y - f * N.y, eta * I.z - f * N.z);
+        } else {
+            D = hemi;
+        }
+    }
+    dir = D;
+    col = col * albedo;
+    if (g.origin_mode == RTPBR_ORIGIN_HIT) {
+        origin = pos;
+    } else {
+        float sgn = dot(D, n) < 0.0f ? -1.0f : 1.0f;
+        vec3 off = (n * g.min_dis) * sgn;
+        origin = origin + off;
+    }
+}
+
+// ---------------------------------------------------------------- F13 sky
+// src/ibl.py:25-29,36-40 + src/util.py:45-50; scene_demo/main.py:245-248,322.  Index clamped (G6).
+RT_D vec3 sky_color(const Params& P, vec3 D) {
+    if (P.cfg.sky_kind == RTPBR_SKY_GRADIENT) {
+        float t = 0.5f * D.y + 0.5f;
+        vec3 g = mix(mk(1.0f, 1.0f, 0.5f), mk(0.25f, 0.35f, 1.0f), t);
+        return g * 1.8f;
+    }
+    if (P.cfg.sky_kind == RTPBR_SKY_ENVMAP && P.env != nullptr) {
+        float u = atan2_(D.z, D.x) * INV_2PI + 0.5f;
+        float v = asin_(D.y) * INV_PI + 0.5f;
+        int x = (int)(u * (float)P.env_w), y = (int)(v * (float)P.env_h);
+        x = x < 0 ? 0 : (x > P.env_w - 1 ? P.env_w - 1 : x);
+        y = y < 0 ? 0 : (y > P.env_h - 1 ? P.env_h - 1 : y);
+        float4 t = P.env[(size_t)x * P.env_h + y];
+        return mk(t.x, t.y, t.z);
+    }
+    return mk(0, 0, 0);
+}
+
+// ---------------------------------------------------------------- F5 camera ray
+// src/camera.py:11-36 (frame precomputed on the host); cornell_box_shortest.py:102-118 pinhole.
+// RNG order: jitter x, jitter y, lens a, lens b.
+RT_D void gen_ray(const Params& P, int px, int py, uint32_t key, uint32_t& cnt, vec3& ro, vec3& rd) {
+    const CamFrame& f = P.cam;
+    float j1 = rng_next(key, cnt), j2 = rng_next(key, cnt);
+    float u, v;
+    vec3 lf = mk(f.lf[0], f.lf[1], f.lf[2]);
+    ro = lf;
+    if (P.cfg.camera_kind == RTPBR_CAMERA_PINHOLE) {
+        u = ((float)px + j1) / (float)P.cfg.width;
+        v = ((float)py + j2) / (float)P.cfg.height;
+    } else {
+        u = ((float)px + j1) * f.inv_w;
+        v = ((float)py + j2) * f.inv_h;
+        float a = rng_next(key, cnt), b = rng_next(key, cnt);
+        float ang = b * 2.0f * PI;
+        float sn, cs;
+        sincos_(ang, &sn, &cs);
+        float r = sqrt_(a);
+        float rx = f.lens_radius * (r * sn), ry = f.lens_radius * (r * cs);
+        vec3 off = fma3(ry, mk(f.y[0], f.y[1], f.y[2]), mk(f.x[0], f.x[1], f.x[2]) * rx);
+        ro = lf + off;
+    }
+    vec3 po = fma3(v, mk(f.ver[0], f.ver[1], f.ver[2]), fma3(u, mk(f.hor[0], f.hor[1], f.hor[2]), mk(f.llc[0], f.llc[1], f.llc[2])));
+    rd = normalize(po - ro);
+}
+
+// ---------------------------------------------------------------- F19 tone map
+// src/postprocessor.py:12-38, src/aces.py:5-30; order per variant
+RT_D vec3 aces_fit(vec3 c, int trunc) {
+    float a1 = trunc ? 0.024578f : 0.0245786f, a2 = trunc ? 0.0000905f : 0.000090537f;
+    const float mi[9] = {0.59719f, 0.35458f, 0.04823f, 0.07600f, 0.90834f, 0.01566f, 0.02840f, 0.13383f, 0.83777f};
+    float mo[9] = {1.60475f, -0.53108f, -0.07367f, -0.10208f, 1.10813f, -0.00605f, -0.00327f, -0.07276f, 1.07602f};
+    if (trunc) {
+        mo[1] = -0.531f;
+        mo[2] = -0.0736f;
+        mo[3] = -0.102f;
+    }
+    vec3 v = mulv(mi, c);
+    float in[3] = {v.x, v.y, v.z}, out[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float x = in[i];
+        float a = x * (x + a1) - a2;
+        float b = x * (0.983729f * x + 0.4329510f) + 0.238081f;
+        out[i] = a / b;
+    }
+    return mulv(mo, mk(out[0], out[1], out[2]));
+}
+RT_D float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
+RT_D vec3 clamp01(vec3 c) { return mk(clamp01(c.x), clamp01(c.y), clamp01(c.z)); }
+RT_D vec3 pow3(vec3 c, float e) { return mk(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+
+RT_D vec3 tone_map(const rtpbr_config& g, float4 b) {
+    vec3 c = mk(b.x / b.w, b.y / b.w, b.z / b.w);
+    c = c * g.exposure;
+    float ig = 1.0f / g.gamma;
+    switch (g.tonemap_order) {
+        case RTPBR_TONEMAP_GAMMA_ACES_CLAMP:
+            return clamp01(aces_fit(pow3(c, ig), g.aces_truncated));
+        case RTPBR_TONEMAP_ACES_GAMMA:
+            return pow3(aces_fit(c, g.aces_truncated), ig);
+        case RTPBR_TONEMAP_ACES_CLAMP_GAMMA:
+            return pow3(clamp01(aces_fit(c, g.aces_truncated)), ig);
+        default:
+            return clamp01(pow3(aces_fit(c, g.aces_truncated), ig));
+    }
+}
+
+// ---------------------------------------------------------------- pixel enumeration
+// Local pixel q (tile-major over the tiles this rank owns, x-major inside a tile, y fastest)
+// -> absolute pixel.  Tile t belongs to rank t % world.
+RT_D bool pixel_of(const Params& P, uint32_t q, int& x, int& y) {
+    uint32_t tpix = (uint32_t)(P.tile_w * P.tile_h);
+    uint32_t tl = q / tpix;
+    uint32_t r = q - tl * tpix;
+    uint32_t lx = r / (uint32_t)P.tile_h;
+    uint32_t ly = r - lx * (uint32_t)P.tile_h;
+    uint32_t tid = (uint32_t)P.rank + tl * (uint32_t)P.world;
+    uint32_t ty = tid / (uint32_t)P.ntx;
+    uint32_t tx = tid - ty * (uint32_t)P.ntx;
+    x = (int)(tx * (uint32_t)P.tile_w + lx);
+    y = (int)(ty * (uint32_t)P.tile_h + ly);
+    return x < P.cfg.width && y < P.cfg.height && ty < (uint32_t)P.nty;
+}
+
+}  // namespace rt

@@ -1,0 +1,433 @@
+// rt_kernels.hip — gfx950 kernels of the per-pixel Monte Carlo sample path.
+//
+//   trace_paths<KIND,NOBJ>   complete-path form (F20/F24: cornell_box_v3/pathtracer.py:81-106,
+//                            renderer.py:27-36).  One wavefront lane per pixel-sample.  Each
+//                            wave is persistent and runs a two-phase state machine:
+//                              phase A  march: all marching lanes take sphere-tracing steps
+//                                       until >= wait_lanes lanes have finished their raycast
+//                                       (ballot + popcount, wave-uniform branch);
+//                              phase B  shade: finished lanes run the surface interaction /
+//                                       miss handling, russian roulette, write finished
+//                                       samples, and idle lanes are REFILLED with fresh
+//                                       pixel-samples (ballot + mbcnt prefix rank into the
+//                                       wave's work range, claimed in chunks from one global
+//                                       atomic) -> live-ray compaction across the bounce loop.
+//                            Per-sample radiance goes to the staging buffer; results do not
+//                            depend on the schedule.
+//   accumulate_samples       adds the staged samples of each pixel IN SAMPLE ORDER into
+//                            image_buffer (T7), exactly like "image_buffer[i,j] += vec4(color,1)".
+//   persistent_steps<KIND>   src/ form (F1-F4,F6,F7: src/pathtracer.py:16-103, src/scene.py:59-84):
+//                            one lane per pixel, ray state in ray_buffer between launches.
+//   refresh, post_process, pack/unpack tiles, math_probe (test hook).
+#include <hip/hip_runtime.h>
+
+#include "rt_device.hpp"
+
+namespace rt {
+
+RT_D uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+RT_D void flush_counters(const Params& P, uint32_t steps, uint32_t raycasts, uint32_t hits, uint32_t sky,
+                         uint32_t samples, uint32_t deposits) {
+    steps = wave_sum(steps);
+    raycasts = wave_sum(raycasts);
+    hits = wave_sum(hits);
+    sky = wave_sum(sky);
+    samples = wave_sum(samples);
+    deposits = wave_sum(deposits);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&P.counters->march_steps, (unsigned long long)steps);
+        atomicAdd(&P.counters->raycasts, (unsigned long long)raycasts);
+        atomicAdd(&P.counters->hits, (unsigned long long)hits);
+        atomicAdd(&P.counters->sky_lookups, (unsigned long long)sky);
+        atomicAdd(&P.counters->samples, (unsigned long long)samples);
+        atomicAdd(&P.counters->deposits, (unsigned long long)deposits);
+    }
+}
+
+// Stage the per-lane-indexed object table (T4: transform + material) in LDS.
+RT_D void stage_objects(const Params& P, ObjFull* lds_obj) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P.objfull);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(lds_obj);
+    const int nw = P.n_obj * (int)(sizeof(ObjFull) / 4);
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// -------------------------------------------------------------------------------------------
+template <int KIND, int NOBJ>
+__global__ void __launch_bounds__(256) trace_paths(const Params P) {
+    __shared__ ObjFull lds_obj[MAX_OBJ];
+    stage_objects(P, lds_obj);
+
+    const int lane = threadIdx.x & 63;
+    Lane L;
+    L.state = ST_IDLE;
+    L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
+    L.o = L.d = L.col = mk(0, 0, 0);
+    L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
+    L.idx = 0;
+    L.steps_left = 0;
+    L.bounce = 0;
+    L.key = L.cnt = L.item = 0;
+    uint32_t n_samples = 0;
+
+    // wave-uniform work range
+    uint32_t next = 0, end = 0;
+    bool drained = false;
+
+    for (;;) {
+        // ================================================================ phase B
+        bool finished = false;
+        bool alive = false;
+        if (L.state == ST_HIT) {
+            // cornell_box_v3/pathtracer.py:97-104
+            const ObjFull o = lds_obj[L.idx];
+            vec3 pos = fma3(L.t_eval, L.d, L.o);
+            surface_interaction<KIND>(P, o, pos, L.o, L.d, L.col, L.key, L.cnt);
+            L.n_hits++;
+            float intensity = brightness(L.col);
+            L.col = L.col * mk(o.emission[0], o.emission[1], o.emission[2]);
+            float visible = brightness(L.col);
+            bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
+            if (stop) {
+                finished = true;
+            } else {
+                L.bounce++;
+                if (L.bounce >= P.cfg.max_raytrace) {
+                    finished = true;  // falls out of the loop keeping the throughput (G4)
+                } else {
+                    // russian roulette :84-89
+                    float inv_pdf = exp_((float)L.bounce / P.cfg.light_quality);
+                    float p = 1.0f - 1.0f / inv_pdf;
+                    if (rng_next(L.key, L.cnt) < p) {
+                        L.col = L.col * p;
+                        finished = true;
+                    } else {
+                        alive = true;
+                    }
+                }
+            }
+        } else if (L.state == ST_MISS) {
+            // :93-95 and the sky variants (tokyo_ibl.py:352-354, bunny_sdf.py:351-354, bunny_sdf_v2.py:355-360)
+            if (P.cfg.sky_kind == RTPBR_SKY_BLACK) {
+                L.col = mk(0, 0, 0);
+            } else if (L.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) {
+                L.col = mk(0, 0, 0);
+            } else if (L.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_WHITE) {
+            } else {
+                L.col = L.col * sky_color(P, L.d);
+                L.n_sky++;
+            }
+            finished = true;
+        }
+        if (finished) {
+            uint32_t q = L.item / (uint32_t)P.K;
+            uint32_t k = L.item - q * (uint32_t)P.K;
+            P.stage[(size_t)k * (size_t)P.np + q] = make_float4(L.col.x, L.col.y, L.col.z, 1.0f);
+            n_samples++;
+            L.state = ST_IDLE;
+        }
+
+        // ---- refill idle lanes with fresh pixel-samples (wave-uniform control flow)
+        {
+            const unsigned long long idle = __ballot(L.state == ST_IDLE);
+            int need = __popcll(idle);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+            int assigned = 0;
+            bool got = false;
+            while (need > 0) {
+                if (next == end) {
+                    if (drained) break;
+                    uint32_t start = 0;
+                    if (lane == 0) start = atomicAdd(P.work_counter, P.chunk);
+                    start = __builtin_amdgcn_readfirstlane(start);
+                    if (start >= P.total_items) {
+                        drained = true;
+                        break;
+                    }
+                    next = start;
+                    uint32_t e = start + P.chunk;
+                    end = e < P.total_items ? e : P.total_items;
+                }
+                int avail = (int)(end - next);
+                int take = need < avail ? need : avail;
+                if (L.state == ST_IDLE && !got && rank >= assigned && rank < assigned + take) {
+                    L.item = next + (uint32_t)(rank - assigned);
+                    got = true;
+                }
+                next += (uint32_t)take;
+                assigned += take;
+                need -= take;
+            }
+            if (L.state == ST_IDLE) {
+                if (got) {
+                    uint32_t q = L.item / (uint32_t)P.K;
+                    uint32_t k = L.item - q * (uint32_t)P.K;
+                    int px, py;
+                    if (pixel_of(P, q, px, py)) {
+                        // renderer.py:32-35: jitter, get_ray, color = 1; then RR at i = 0 (p = 0, draw consumed)
+                        L.key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, P.sample_base + k);
+                        L.cnt = 0;
+                        gen_ray(P, px, py, L.key, L.cnt, L.o, L.d);
+                        L.col = mk(1, 1, 1);
+                        L.bounce = 0;
+                        float inv_pdf = exp_(0.0f / P.cfg.light_quality);
+                        float p = 1.0f - 1.0f / inv_pdf;
+                        if (rng_next(L.key, L.cnt) < p) {
+                            L.col = L.col * p;
+                            P.stage[(size_t)k * (size_t)P.np + q] = make_float4(L.col.x, L.col.y, L.col.z, 1.0f);
+                            n_samples++;
+                        } else {
+                            alive = true;
+                        }
+                    } else {
+                        // padding pixel of an edge tile: nothing to trace, stays idle until the next refill
+                        P.stage[(size_t)k * (size_t)P.np + q] = make_float4(0, 0, 0, 0);
+                    }
+                } else if (drained) {
+                    L.state = ST_EXHAUSTED;
+                }
+            }
+        }
+        if (alive) march_init(P, L);
+
+        // ================================================================ phase A
+        unsigned long long marching = __ballot(L.state == ST_MARCH);
+        if (marching == 0) {
+            // nothing to march: either everything is exhausted, or only idle padding lanes remain
+            if (__ballot(L.state != ST_EXHAUSTED) == 0) break;
+            continue;
+        }
+        const int n_active = __popcll(__ballot(L.state != ST_EXHAUSTED));
+        int kstar = P.wait_lanes;
+        const int cap = n_active >> 2 > 1 ? n_active >> 2 : 1;
+        kstar = (drained && kstar > cap) ? cap : kstar;
+        int n_march;
+        do {
+            if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+            n_march = __popcll(__ballot(L.state == ST_MARCH));
+        } while (n_march > 0 && (n_active - n_march) < kstar);
+    }
+    flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, 0);
+}
+
+// -------------------------------------------------------------------------------------------
+// image_buffer[i,j] += vec4(color, 1) for k = 0..K-1 in order (renderer.py:36)
+__global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (uint32_t)P.np) return;
+    int x, y;
+    if (!pixel_of(P, q, x, y)) return;
+    float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
+    float4 acc = *dst;
+    for (int k = 0; k < P.K; k++) {
+        float4 c = P.stage[(size_t)k * (size_t)P.np + q];
+        acc.x += c.x;
+        acc.y += c.y;
+        acc.z += c.z;
+        acc.w += 1.0f;
+    }
+    *dst = acc;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { /* deposits are counted on the host: pixels*K */ }
+}
+
+// -------------------------------------------------------------------------------------------
+// src/ persistent-ray form: russian_roulette -> track_once -> raytrace (src/pathtracer.py:16-91),
+// raycast src/scene.py:59-84.  One lane per owned pixel; `steps` bounce-steps per launch.
+template <int KIND>
+__global__ void __launch_bounds__(256) persistent_steps(const Params P, int steps) {
+    __shared__ ObjFull lds_obj[MAX_OBJ];
+    stage_objects(P, lds_obj);
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    int px = 0, py = 0;
+    bool valid = q < (uint32_t)P.np && pixel_of(P, q, px, py);
+    uint32_t n_steps = 0, n_raycasts = 0, n_hits = 0, n_sky = 0, n_samples = 0, n_dep = 0;
+    if (valid) {
+        const rtpbr_config& g = P.cfg;
+        size_t pi = (size_t)px * g.height + py;
+        rtpbr_ray rb = P.ray_buffer[pi];
+        vec3 o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
+        vec3 d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
+        vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]);
+        int depth = rb.depth;
+        float4 acc = P.image_buffer[pi];
+        for (int s = 0; s < steps; s++) {
+            uint32_t key = rng_key(g.seed, (uint32_t)px, (uint32_t)py, P.sample_base + (uint32_t)s), cnt = 0;
+            // russian_roulette :65-77
+            float p = (depth == 0) ? 1.0f : g.quality_per_sample;
+            p -= (float)depth * (1.0f / (float)g.max_raytrace);
+            if (rng_next(key, cnt) > p) {
+                col = mk(0, 0, 0);
+                depth = -depth;
+            } else {
+                col = col * (1.0f / p);
+                // track_once :53-62
+                if (depth < 1 || depth > g.max_raytrace) {
+                    acc.x += col.x;
+                    acc.y += col.y;
+                    acc.z += col.z;
+                    acc.w += 1.0f;
+                    n_dep++;
+                    gen_ray(P, px, py, key, cnt, o, d);
+                    col = mk(1, 1, 1);
+                    depth = 0;
+                }
+                // raycast src/scene.py:59-84
+                float t = 0.0f, w = g.omega0, sstep = 0.0f, dist = g.max_dis;
+                int idx = 0;
+                bool hit = false;
+                for (int it = 0; it < g.max_raymarch; it++) {
+                    float ld = dist;
+                    nearest<KIND, 0>(P, o, idx, dist);
+                    n_steps++;
+                    if (w > 1.0f && ld + dist < sstep) {
+                        sstep -= w * sstep;
+                        w = 1.0f;
+                        t += sstep;
+                        o = fma3(sstep, d, o);
+                        continue;
+                    }
+                    sstep = w * dist;
+                    t += sstep;
+                    o = fma3(sstep, d, o);
+                    hit = dist < t * g.hit_eps;
+                    if (hit || t >= g.max_dis) break;
+                }
+                depth += 1;
+                n_raycasts++;
+                // raytrace :16-36
+                if (hit) {
+                    const ObjFull ob = lds_obj[idx];
+                    surface_interaction<KIND>(P, ob, o, o, d, col, key, cnt);
+                    n_hits++;
+                    float intensity = brightness(col);
+                    col = col * mk(ob.emission[0], ob.emission[1], ob.emission[2]);
+                    float visible = brightness(col);
+                    bool stop = intensity < visible || visible < g.vis_lo || visible > g.vis_hi;
+                    if (stop) depth = -depth;
+                } else {
+                    depth = -depth;
+                    col = col * sky_color(P, d);
+                    n_sky++;
+                    if (g.primary_miss == RTPBR_PRIMARY_BLACK) col = col * (depth < -1 ? 1.0f : 0.0f);
+                }
+            }
+            n_samples++;
+        }
+        rb.origin[0] = o.x; rb.origin[1] = o.y; rb.origin[2] = o.z;
+        rb.direction[0] = d.x; rb.direction[1] = d.y; rb.direction[2] = d.z;
+        rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
+        rb.depth = depth;
+        P.ray_buffer[pi] = rb;
+        P.image_buffer[pi] = acc;
+    }
+    flush_counters(P, n_steps, n_raycasts, n_hits, n_sky, n_samples, n_dep);
+}
+
+// -------------------------------------------------------------------------------------------
+// refresh() src/renderer.py:12-22
+__global__ void refresh_kernel(float4* image_buffer, rtpbr_ray* ray_buffer, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    image_buffer[i] = make_float4(0, 0, 0, 0);
+    ray_buffer[i].depth = 0;
+}
+
+// post_process() src/postprocessor.py:24-43
+__global__ void post_process_kernel(const Params P) {
+    size_t n = (size_t)P.cfg.width * P.cfg.height;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vec3 c = tone_map(P.cfg, P.image_buffer[i]);
+    P.image_pixels[i * 3 + 0] = c.x;
+    P.image_pixels[i * 3 + 1] = c.y;
+    P.image_pixels[i * 3 + 2] = c.z;
+}
+
+// tile pack / unpack for the multi-GPU gather
+__global__ void pack_tiles_kernel(const Params P, float4* dst) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (uint32_t)P.np) return;
+    int x, y;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (pixel_of(P, q, x, y)) v = P.image_buffer[(size_t)x * P.cfg.height + y];
+    dst[q] = v;
+}
+__global__ void unpack_tiles_kernel(const Params P, const float4* src) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (uint32_t)P.np) return;
+    int x, y;
+    if (pixel_of(P, q, x, y)) P.image_buffer[(size_t)x * P.cfg.height + y] = src[q];
+}
+
+// test hook: evaluate one of the exact math functions on the device (tests/test_gpu_math.py)
+__global__ void math_probe(int op, const float* a, const float* b, float* out, float* out2, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f;
+    float r = 0.0f, r2 = 0.0f;
+    switch (op) {
+        case 0: sincos_(x, &r, &r2); break;
+        case 1: r = exp_(x); break;
+        case 2: r = atan2_(x, y); break;
+        case 3: r = asin_(x); break;
+        case 4: r = sqrt_(x); break;
+        case 5: r = x / y; break;
+        case 6: { uint32_t n0 = __builtin_bit_cast(uint32_t, y); r = rng_next(__builtin_bit_cast(uint32_t, x), n0); } break;
+        default: break;
+    }
+    out[i] = r;
+    if (out2) out2[i] = r2;
+}
+
+// ---- launchers used by rt_capi.hip -------------------------------------------------------
+void launch_trace(const Params& P, int kind, int grid, hipStream_t st) {
+    if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_BOXES) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 0>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((trace_paths<KIND_GENERIC, 0>), dim3(grid), dim3(256), 0, st, P);
+}
+int trace_blocks_per_cu(int kind, int n_obj) {
+    int per_cu = 0;
+    hipError_t e;
+    if (kind == KIND_BOXES && n_obj == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 8>, 256, 0);
+    else if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 0>, 256, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_GENERIC, 0>, 256, 0);
+    return e == hipSuccess ? per_cu : 0;
+}
+void launch_accumulate(const Params& P, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    hipLaunchKernelGGL(accumulate_samples, dim3(grid), dim3(256), 0, st, P);
+}
+void launch_persistent(const Params& P, int kind, int steps, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((persistent_steps<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P, steps);
+    else hipLaunchKernelGGL((persistent_steps<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
+}
+void launch_refresh(float4* ib, rtpbr_ray* rb, size_t n, hipStream_t st) {
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(refresh_kernel, dim3(grid), dim3(256), 0, st, ib, rb, n);
+}
+void launch_post_process(const Params& P, hipStream_t st) {
+    size_t n = (size_t)P.cfg.width * P.cfg.height;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(post_process_kernel, dim3(grid), dim3(256), 0, st, P);
+}
+void launch_pack(const Params& P, float4* dst, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    hipLaunchKernelGGL(pack_tiles_kernel, dim3(grid), dim3(256), 0, st, P, dst);
+}
+void launch_unpack(const Params& P, const float4* src, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, st, P, src);
+}
+void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st) {
+    int grid = (n + 255) / 256;
+    hipLaunchKernelGGL(math_probe, dim3(grid), dim3(256), 0, st, op, a, b, out, out2, n);
+}
+
+}  // namespace rt

@@ -1,0 +1,180 @@
+// rt_math.hpp — exactly specified f32 arithmetic for the gfx950 kernels.
+//
+// The reference computes in IEEE f32 through Taichi (src/config.py:5 default_fp=ti.f32);
+// Taichi's own math library rounding is not reproducible.  This
+// build pins every operation to something IEEE-754 defines exactly so that results are a
+// pure function of the inputs on any conforming machine:
+//   + - * /  sqrt  fma : correctly rounded (hipcc default for f32 divide/sqrt; the
+//                        translation unit is compiled with -ffp-contract=off, so the only
+//                        fused operations are the __builtin_fmaf written here);
+//   sin cos exp atan2 asin : fixed polynomial kernels (Cephes single-precision
+//                        coefficients) evaluated with the exact ops above.
+// These run once per path segment (lens, hemisphere, roulette, sky), never in the march
+// loop, so they cost <1 % of a sample; the march loop itself is mul/add/fma/min/max/sqrt.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_HD __host__ __device__ __forceinline__
+#define RT_D __device__ __forceinline__
+
+namespace rt {
+
+constexpr float PI = 3.14159274f;
+constexpr float TWO_OVER_PI = 0.636619747f;
+constexpr float INV_2PI = 0.159154937f;   // src/util.py:48  0.5/pi
+constexpr float INV_PI = 0.318309873f;
+constexpr float DEG2RAD = 0.0174532924f;  // taichi.math.radians
+
+struct vec3 {
+    float x, y, z;
+};
+
+RT_HD vec3 mk(float x, float y, float z) { return vec3{x, y, z}; }
+RT_HD vec3 operator+(vec3 a, vec3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD vec3 operator-(vec3 a, vec3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD vec3 operator*(vec3 a, vec3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD vec3 operator*(vec3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RT_HD vec3 operator-(vec3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// a + s*b, fused per component
+RT_HD vec3 fma3(float s, vec3 b, vec3 a) { return mk(fma_(s, b.x, a.x), fma_(s, b.y, a.y), fma_(s, b.z, a.z)); }
+RT_HD float dot(vec3 a, vec3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+RT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
+RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
+RT_HD vec3 normalize(vec3 a) {
+    float inv = 1.0f / sqrt_(dot(a, a));
+    return a * inv;
+}
+RT_HD vec3 cross(vec3 a, vec3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_HD float mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+RT_HD vec3 mix(vec3 x, vec3 y, float a) {
+    float b = 1.0f - a;
+    return mk(x.x * b + y.x * a, x.y * b + y.y * a, x.z * b + y.z * a);
+}
+RT_HD float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+RT_HD float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+RT_HD float fabs_(float a) { return __builtin_fabsf(a); }
+// row-major 3x3 times column vector
+RT_HD vec3 mulv(const float* m, vec3 v) {
+    return mk(fma_(m[2], v.z, fma_(m[1], v.y, m[0] * v.x)), fma_(m[5], v.z, fma_(m[4], v.y, m[3] * v.x)),
+              fma_(m[8], v.z, fma_(m[7], v.y, m[6] * v.x)));
+}
+
+// sin/cos: Cody-Waite reduction by pi/2 + Cephes sinf/cosf kernels on [-pi/4, pi/4]
+RT_HD void sincos_(float a, float* s_out, float* c_out) {
+    float kf = __builtin_rintf(a * TWO_OVER_PI);
+    int k = (int)kf;
+    float r = fma_(kf, -1.5703125f, a);
+    r = fma_(kf, -4.83751296997070312e-4f, r);
+    r = fma_(kf, -7.54978995489188e-8f, r);
+    float r2 = r * r;
+    float ps = fma_(fma_(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float sn = fma_(r * r2, ps, r);
+    float pc = fma_(fma_(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    float cs = fma_(r2 * r2, pc, fma_(-0.5f, r2, 1.0f));
+    bool swap = (k & 1) != 0;
+    float s = swap ? cs : sn;
+    float c = swap ? sn : cs;
+    if (k & 2) s = -s;
+    if ((k + 1) & 2) c = -c;
+    *s_out = s;
+    *c_out = c;
+}
+RT_HD float sin_(float a) {
+    float s, c;
+    sincos_(a, &s, &c);
+    return s;
+}
+
+// exp: Cephes expf
+RT_HD float exp_(float x) {
+    float kf = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma_(kf, -0.693359375f, x);
+    r = fma_(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    float e = fma_(p, r * r, r) + 1.0f;
+    int k = (int)kf;
+    k = k > 127 ? 127 : k;
+    k = k < -126 ? -126 : k;
+    uint32_t bits = (uint32_t)(k + 127) << 23;
+    return e * __builtin_bit_cast(float, bits);
+}
+
+RT_HD float atan_pos_(float x) {
+    float y0, z;
+    if (x > 2.414213562373095f) {
+        y0 = 1.5707963267948966f;
+        z = -1.0f / x;
+    } else if (x > 0.4142135623730950f) {
+        y0 = 0.7853981633974483f;
+        z = (x - 1.0f) / (x + 1.0f);
+    } else {
+        y0 = 0.0f;
+        z = x;
+    }
+    float zz = z * z;
+    float p = 8.05374449538e-2f;
+    p = fma_(p, zz, -1.38776856032e-1f);
+    p = fma_(p, zz, 1.99777106478e-1f);
+    p = fma_(p, zz, -3.33329491539e-1f);
+    return y0 + fma_(p * zz, z, z);
+}
+RT_HD float atan2_(float y, float x) {
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    float ax = fabs_(x), ay = fabs_(y);
+    float a = (ax == 0.0f) ? 1.5707963267948966f : atan_pos_(ay / ax);
+    if (x < 0.0f) a = PI - a;
+    return (y < 0.0f) ? -a : a;
+}
+// asin with the argument clamped to [-1,1] (the reference would return NaN outside)
+RT_HD float asin_(float x) {
+    float a = fabs_(x);
+    if (a > 1.0f) a = 1.0f;
+    bool big = a > 0.5f;
+    float z, w;
+    if (big) {
+        z = 0.5f * (1.0f - a);
+        w = sqrt_(z);
+    } else {
+        w = a;
+        z = a * a;
+    }
+    float p = 4.2163199048e-2f;
+    p = fma_(p, z, 2.4181311049e-2f);
+    p = fma_(p, z, 4.5470025998e-2f);
+    p = fma_(p, z, 7.4953002686e-2f);
+    p = fma_(p, z, 1.6666752422e-1f);
+    float r = fma_(p * z, w, w);
+    if (big) r = 1.5707963267948966f - (r + r);
+    return (x < 0.0f) ? -r : r;
+}
+
+// counter-based RNG replacing ti.random(): stream key from
+// (seed, pixel x, pixel y, sample index); draw n = murmur3-finalised counter; 24-bit mantissa.
+RT_HD uint32_t mix32(uint32_t z) {
+    z ^= z >> 16;
+    z *= 0x85ebca6bU;
+    z ^= z >> 13;
+    z *= 0xc2b2ae35U;
+    z ^= z >> 16;
+    return z;
+}
+RT_HD uint32_t rng_key(uint32_t seed, uint32_t x, uint32_t y, uint32_t sample) {
+    uint32_t k = mix32(seed + 0x9E3779B9U);
+    k = mix32(k ^ (x | (y << 16)));
+    k = mix32(k ^ sample);
+    return k;
+}
+RT_HD float rng_next(uint32_t key, uint32_t& n) {
+    uint32_t z = mix32(key + n * 0x9E3779B9U);
+    n++;
+    return (float)(z >> 8) * 5.9604644775390625e-8f;
+}
+
+}  // namespace rt

@@ -1,0 +1,89 @@
+// rt_types.hpp — device-side layout of the scene, camera frame and launch parameters.
+//
+// HBM / kernarg / LDS placement:
+//   Params (kernarg, constant address space -> s_load into SGPRs): config knobs, camera
+//     frame, work geometry, and ObjM[n]: the per-object constants the MARCH LOOP reads
+//     (position, world->local matrix, shape params).  They are wave-uniform, so they are
+//     consumed as scalar operands and cost no VGPRs and no LDS bandwidth.
+//   ObjFull[n] (HBM -> LDS once per workgroup): transform + material of every object,
+//     gathered PER LANE by hit-object index in the shading phase (T4).
+//   stage (HBM): one float4 per pixel-sample of the current sub-launch, [k][q] (q fastest),
+//     reduced in sample order into image_buffer (T7) by the accumulate kernel.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/rtpbr.h"
+#include "rt_math.hpp"
+
+namespace rt {
+
+constexpr int MAX_OBJ = RTPBR_MAX_OBJECTS;
+static_assert(sizeof(rtpbr_config) == 152 && sizeof(rtpbr_object) == 116 && sizeof(rtpbr_camera) == 52 &&
+                  sizeof(rtpbr_ray) == 40,
+              "C-ABI struct layout changed");
+
+// 16 dwords: what one march step needs from one object
+struct ObjM {
+    float px, py, pz;
+    float m[9];
+    float sx, sy, sz;
+    int32_t type;
+};
+static_assert(sizeof(ObjM) == 64, "ObjM must be 64 bytes");
+
+// transform + material for the shading phase, gathered per lane (stored in LDS)
+struct ObjFull {
+    float px, py, pz;
+    float m[9];
+    float sx, sy, sz;
+    int32_t type;
+    float albedo[3];
+    float emission[3];
+    float roughness, metallic, transmission, ior;
+    float pad[2];
+};
+static_assert(sizeof(ObjFull) == 112, "ObjFull must be 112 bytes");
+
+// camera frame precomputed on the host with the same op order the oracle uses
+// (src/camera.py:11-36): only the per-sample part runs on the device.
+struct CamFrame {
+    float lf[3], x[3], y[3], llc[3], hor[3], ver[3];
+    float lens_radius;
+    float inv_w, inv_h;
+};
+
+struct Counters {
+    unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
+};
+
+struct Params {
+    rtpbr_config cfg;
+    CamFrame cam;
+    int32_t n_obj;
+    // bunny animation (bunny_sdf_glass.py:213-217): sin/cos of t = pi*frame/120, host-computed
+    float anim_s, anim_c;
+    // work geometry
+    uint32_t sample_base;   // absolute index of the first sample (or bounce-step) of this launch
+    int32_t K;              // samples per pixel in this sub-launch
+    int32_t tile_w, tile_h, ntx, nty, rank, world;
+    int32_t n_local_tiles;  // tiles owned by this rank
+    int32_t np;             // padded local pixel count = n_local_tiles*tile_w*tile_h
+    uint32_t total_items;   // np*K
+    uint32_t chunk;         // work items claimed per atomic
+    int32_t wait_lanes;     // k*: leave the march phase when this many lanes wait for shading
+    // pointers
+    float4* stage;
+    float4* image_buffer;   // T7 (W,H) float4
+    float* image_pixels;    // T8 (W,H,3)
+    rtpbr_ray* ray_buffer;  // T6
+    const ObjFull* objfull;
+    const float4* env;      // T9 as float4 texels [x][y]
+    int32_t env_w, env_h;
+    const float* bunny;     // 625 weights
+    unsigned int* work_counter;
+    Counters* counters;
+    ObjM objm[MAX_OBJ];
+};
+static_assert(sizeof(Params) < 3900, "Params must fit the 4 KB kernarg segment");
+
+}  // namespace rt

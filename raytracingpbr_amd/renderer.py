@@ -67,6 +67,11 @@ class Renderer:
         self.api.call("set_env", self._ctx, t.ctypes.data_as(C.c_void_p), t.shape[0], t.shape[1], fmt,
                       float(exposure), float(gamma))
 
+    def set_shape_data(self, shape: int, data: np.ndarray):
+        """Per-shape data blob; the bunny MLP's 625 weights (bunny_sdf_glass.py:157-201)."""
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        self.api.call("set_shape_data", self._ctx, int(shape), d.ctypes.data_as(C.c_void_p), d.size)
+
     def set_tiles(self, tile_w, tile_h, rank, world):
         self.api.call("set_tiles", self._ctx, tile_w, tile_h, rank, world)
         self.tiles = (tile_w, tile_h, rank, world)
