@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): Cornell Box 1920x1080, 256 spp, 8 bounces, the
+cornell_box_v3 variant of the reference (examples/cornell_box/cornell_box_v3).  One "step" =
+one complete render of that frame: refresh, 256 samples per pixel through the HIP trace
+kernel (+ ordered accumulation), and for N > 1 the single RCCL gather of the per-tile
+radiance to rank 0.  Inputs (scene constants, camera) are resident on the device before the
+timed region.  N ranks share the FIXED frame (tiles dealt round-robin) -> strong scaling.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is the HBM view the metric asks for (algorithmic
+bytes of SURVEY.md §8(d) / trace-kernel time vs 8 TB/s — tiny, this path is VALU bound);
+`valu` is the bound that actually applies (algorithmic FLOPs of §8(d) vs the 78.6 TFLOP/s
+non-packed FP32 vector peak).  `cpu_baseline` = the CPU oracle (a port of the reference
+path; Taichi itself is unavailable) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 78.6        # non-packed f32 FMA: 256 CU x 4 SIMD x 32 lanes x 2 FLOP x 2.4 GHz
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--wait-lanes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sc, cfg, budget_s):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleRenderer
+    cores = os.cpu_count() or 1
+    o = OracleRenderer(sc, cfg, threads=cores)
+    t0 = time.perf_counter()
+    o.sample(1)
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(64, (budget_s - t1) / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    o.sample(n)
+    dt = time.perf_counter() - t0
+    samples = cfg.width * cfg.height * n
+    return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cfg.width}x{cfg.height} x {n} spp, {cfg.max_raytrace} bounces ({samples / 1e6:.1f} Msamples, {dt:.1f} s), "
+                      f"C restatement of the reference path with OpenMP over {cores} threads (Taichi unavailable)"}
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from raytracingpbr_amd import Config, Renderer, cornell_box
+    from raytracingpbr_amd.distributed import TileGather
+
+    W, H, SPP = a.width, a.height, a.spp
+    cfg = Config.cornell_v3(W, H, seed=0, max_raytrace=a.bounces)
+    sc = cornell_box("v3", aspect=W / H)
+    r = Renderer(sc, cfg, device=local_rank)
+    if a.wait_lanes:
+        r.set_option("wait_lanes", a.wait_lanes)
+    dev = torch.device("cuda", local_rank)
+    tg = TileGather(r, rank, world, device=dev) if world > 1 else None
+
+    def step():
+        r.refresh()
+        r.sample(SPP)
+        if tg is not None:
+            tg.gather()
+
+    def fence():
+        r.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    trace_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        # HIP-event timing of the dominant kernel (recorded on the context's own stream);
+        # reading it waits for the step, which the timed region must wait for anyway
+        tr, _tot, n = r.last_sample_ms()
+        trace_ms += tr
+        launches += n
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    c = r.counters()                                  # this rank, last step
+    if rank == 0:
+        total_samples = W * H * SPP * a.steps
+        value = total_samples / dt / 1e6
+        # ---- per-launch figures of the dominant kernel (trace_paths) on this rank
+        avg_launch_s = trace_ms / 1e3 / max(launches, 1)
+        samples_per_launch = c.samples * a.steps / max(launches, 1)
+        k_per_launch = SPP * a.steps / max(launches, 1)
+        sky_frac = c.sky_lookups / max(c.samples, 1)
+        bytes_per_sample = 32.0 / k_per_launch + 12.0 * sky_frac       # SURVEY.md §8(d), reference layout
+        alg_bytes = bytes_per_sample * samples_per_launch
+        achieved_gbs = alg_bytes / avg_launch_s / 1e9
+        B = c.raycasts / max(c.samples, 1)
+        S = c.march_steps / max(c.raycasts, 1)
+        flop_per_sample = 110.0 + B * (S * 338.0 + 197.0 + 110.0 + 25.0) + sky_frac * 15.0   # §8(d) Cornell figures
+        achieved_tflops = flop_per_sample * samples_per_launch / avg_launch_s / 1e12
+        out = {
+            "metric": "Msamples/sec (pixels x spp / s), Cornell Box 1920x1080",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell Box (cornell_box_v3 variant) {W}x{H}, {SPP} spp, {a.bounces} bounces, "
+                                   f"seed 0; one step = refresh + {SPP} spp trace + ordered accumulation"
+                                   + (f" + 1 RCCL gather of {world} tile sets" if world > 1 else ""),
+                       "parallelism": f"tiles{world}" if world > 1 else "single",
+                       "raycasts_per_sample": round(B, 3), "march_steps_per_raycast": round(S, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 8), "traffic": None,
+                         "kernel": "trace_paths", "avg_launch_ms": round(avg_launch_s * 1e3, 3),
+                         "algorithmic_bytes_per_launch": round(alg_bytes), "launches_timed": launches,
+                         "note": "HBM view requested by the metric; the kernel is FP32-VALU bound, see valu"},
+            "valu": {"bound": "fp32-valu (non-packed FMA)", "achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 4),
+                     "algorithmic_flop_per_sample": round(flop_per_sample)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, cfg, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -730,6 +730,12 @@ int rto_set_bunny_weights(const float* w, int n) {
     memcpy(g_bunny, w, sizeof g_bunny); g_bunny_set = 1; return RTPBR_OK;
 }
 
+int rto_set_shape_data(struct rto_ctx* c, int shape, const float* data, int n) {
+    (void)c;
+    if (shape != RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "only the bunny takes shape data");
+    return rto_set_bunny_weights(data, n);
+}
+
 /* ------------------------------------------------------------------ test hooks (K1 known answers) */
 float rto_test_sdf(int type, const float* p, const float* s, float rho) {
     return sdf_shape(type, v3_make(p[0], p[1], p[2]), s, rho, 1e3f);

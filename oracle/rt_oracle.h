@@ -31,6 +31,7 @@ int rto_get_counters(struct rto_ctx* c, rtpbr_counters* out);
 int rto_set_threads(struct rto_ctx* c, int n);
 int rto_set_sample_base(struct rto_ctx* c, uint32_t base);
 int rto_set_bunny_weights(const float* w, int n);
+int rto_set_shape_data(struct rto_ctx* c, int shape, const float* data, int n);
 void rto_rotate(const float* rad, float* m);
 #ifdef __cplusplus
 }

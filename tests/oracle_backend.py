@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "librt_oracle.so")
 _OPTIONAL = ("packed_bytes", "pack_tiles", "unpack_tiles", "last_sample_ms", "get_stream", "set_option",
-             "set_shape_data", "test_math")
+             "test_math")
 
 _api = None
 
@@ -33,11 +33,6 @@ def oracle_api():
         lib = _api.lib
         lib.rto_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib.rto_set_sample_base.argtypes = [C.c_void_p, C.c_uint32]
-        lib.rto_set_bunny_weights.argtypes = [C.c_void_p, C.c_int]
-        w = os.path.join(ROOT, "raytracingpbr_amd", "data", "bunny_weights.npy")
-        if os.path.exists(w):
-            arr = np.ascontiguousarray(np.load(w), dtype=np.float32)
-            lib.rto_set_bunny_weights(arr.ctypes.data_as(C.c_void_p), arr.size)
     return _api
 
 

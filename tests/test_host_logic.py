@@ -1,0 +1,110 @@
+"""Host-side logic that needs no GPU: struct layouts, presets, tile layout, the C-ABI
+library's exported symbols, error behaviour."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracingpbr_amd as rt
+from raytracingpbr_amd import _capi
+from raytracingpbr_amd.config import Config
+from raytracingpbr_amd.tiles import TileLayout, default_tile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(Config) == 152
+    assert C.sizeof(rt.Ray) == 40 and C.sizeof(rt.Material) == 40 and C.sizeof(rt.Transform) == 72
+    assert C.sizeof(rt.SDFObject) == 116 and C.sizeof(rt.Camera) == 52
+    # field order of Config == field order of rtpbr_config in include/rtpbr.h
+    hdr = open(os.path.join(ROOT, "include", "rtpbr.h")).read()
+    body = hdr[hdr.index("typedef struct rtpbr_config {"):hdr.index("} rtpbr_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for line in body.split("\n")[1:]:
+        m = re.match(r"\s*(?:int32_t|uint32_t|float)\s+([^;]+);", line)
+        if m:
+            names += [n.strip() for n in m.group(1).split(",")]
+    assert names == [n for n, _ in Config._fields_]
+
+
+def test_presets_follow_reference_constants():
+    c = Config.cornell_v3(512, 512)
+    assert c.max_raymarch == 512 and c.max_raytrace == 3 and c.min_dis == pytest.approx(0.05)
+    assert c.hit_eps == pytest.approx(0.5 / 512) and c.normal_h == pytest.approx(0.5773 * 0.005)
+    assert c.light_quality == 128 and c.box_round == pytest.approx(0.01)
+    s = Config.src()
+    assert (s.width, s.height) == (768, 432) and s.kernel_form == rt.FORM.PERSISTENT_RAY
+    assert s.hit_eps == pytest.approx(1 / 768) and s.min_dis == pytest.approx(2.5 / 768) and s.max_dis == 1e3
+    assert s.vis_lo == pytest.approx(1e-4) and s.vis_hi == pytest.approx(1e4) and s.quality_per_sample == pytest.approx(0.8)
+    b = Config.bunny_glass()
+    assert b.max_raymarch == 2048 and b.omega0 == 0.5 and b.light_quality == 512 and b.exposure == pytest.approx(0.8)
+    t = Config.tokyo_ibl()
+    assert t.omega_guard == 0 and t.omega_fb_a == 0.5 and t.omega_fb_b == 0.5 and t.fresnel_kind == 1
+    with pytest.raises(AttributeError):
+        c.copy(no_such_field=1)
+
+
+def test_tile_layout_partition():
+    lay = TileLayout(100, 60, 16, 16, 3)
+    assert lay.ntx == 7 and lay.nty == 4 and lay.n_tiles == 28 and lay.n_local_tiles == 10
+    own = lay.owner_map()
+    seen = np.zeros((100, 60), int)
+    for r in range(3):
+        x, y, v = lay.pixel_index(r)
+        assert len(x) == lay.packed_pixels == 10 * 256
+        assert np.all(own[x[v], y[v]] == r)
+        seen[x[v], y[v]] += 1
+    assert np.all(seen == 1)                         # every pixel owned exactly once
+    img = np.random.default_rng(0).random((100, 60, 4)).astype(np.float32)
+    out = np.zeros_like(img)
+    for r in range(3):
+        lay.unpack_into(out, lay.pack(img, r), r)
+    assert np.array_equal(out, img)
+    assert default_tile(1920, 1080, 1) == (1920, 1080)
+    tw, th = default_tile(1920, 1080, 8)
+    assert ((1920 + tw - 1) // tw) * ((1080 + th - 1) // th) >= 8 * 16
+
+
+def test_hip_library_exports_every_declared_symbol():
+    """The C-ABI library loads without a GPU and exports every function include/rtpbr.h
+    declares (no compute calls here)."""
+    assert os.path.exists(_capi.HIP_LIB_PATH), "build the HIP library first: python -m raytracingpbr_amd.build"
+    hdr = open(os.path.join(ROOT, "include", "rtpbr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(rtpbr_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 24
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted("rtpbr_" + n for n in _capi.ENTRY_POINTS) == declared
+    lib.rtpbr_backend.restype = C.c_char_p
+    assert lib.rtpbr_backend() == b"hip-gfx950"
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        _capi.CApi(str(tmp_path / "nope.so"))
+
+
+def test_product_package_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under raytracingpbr_amd/ may mention it."""
+    pkg = os.path.join(ROOT, "raytracingpbr_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "rt_oracle" not in txt and "librt_oracle" not in txt and "rto_" not in txt, os.path.join(dp, f)
+
+
+def test_synthetic_env_is_deterministic():
+    import hashlib
+    from raytracingpbr_amd.ibl import preprocess, synthetic_env
+    e = synthetic_env(384, 192)
+    assert e.shape == (384, 192, 3) and e.dtype == np.uint8
+    assert hashlib.sha1(e.tobytes()).hexdigest() == "2606c581d11bcf02e1cd7047fa6ba08fa0f64640"
+    p = preprocess(e, 1.4, 2.2)
+    assert p.dtype == np.float32 and p.max() == pytest.approx(1.4 ** 2.2, rel=1e-5)   # 2.10
