@@ -24,6 +24,7 @@ void launch_pack(const Params& P, float4* dst, hipStream_t st);
 void launch_unpack(const Params& P, const float4* src, hipStream_t st);
 void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st);
 int trace_blocks_per_cu(int kind, int n_obj);
+void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 }  // namespace rt
 
 using namespace rt;
@@ -608,5 +609,19 @@ extern "C" int rtpbr_test_math(rtpbr_ctx* c, int op, const float* a, const float
     (void)hipFree(db);
     (void)hipFree(dout);
     (void)hipFree(dout2);
+    return RTPBR_OK;
+}
+
+// test hook: exhaustive check of the device sqrt_ against IEEE sqrt; *mismatches must come back 0
+extern "C" int rtpbr_test_sqrt_exhaustive(rtpbr_ctx* c, unsigned long long* mismatches) {
+    if (!c || !mismatches) return fail(RTPBR_EINVAL, "null argument");
+    if (int r = set_dev(c)) return r;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof *d));
+    HIP_TRY(hipMemset(d, 0, sizeof *d));
+    launch_sqrt_exhaustive(d, c->stream);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(mismatches, d, sizeof *d, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
     return RTPBR_OK;
 }

@@ -5,6 +5,8 @@
 // F15 sampling helpers, F19 tone map, F23 neural bunny SDF.  Each cites the reference lines
 // whose behaviour it reproduces; arithmetic follows rt_math.hpp (exact ops, fixed order).
 #pragma once
+#include <cstddef>
+
 #include "rt_types.hpp"
 
 namespace rt {
@@ -118,24 +120,44 @@ RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p) {
 
 // ---------------------------------------------------------------- F8 nearest
 // min_i |sdf_i|, ties to the lowest index (cornell_box_v3/pathtracer.py:41-49; src/scene.py:44-56).
-// The object table is read from the kernarg segment at wave-uniform indices -> scalar loads.
+// The march-loop object table lives in the kernarg segment (constant address space) and is
+// read at wave-uniform indices -> s_load_dwordx16 into SGPRs, consumed as scalar operands.
+// The pointer is laundered through an empty asm every call so the loads stay INSIDE the march
+// loop: hoisting 8 x 16 constants out of it needs more SGPRs than exist and the compiler then
+// spills them into VGPR lanes (v_writelane/v_readlane per constant per step).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) ObjM* ObjTab;
+RT_D ObjTab obj_table() {
+    const __attribute__((address_space(4))) char* k =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return (ObjTab)(k + offsetof(Params, objm));
+}
+#else
+typedef const ObjM* ObjTab;   // host pass only parses the device functions
+RT_D ObjTab obj_table() { return nullptr; }
+#endif
+
 template <int KIND, int NOBJ>
 RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
     const int n = NOBJ > 0 ? NOBJ : P.n_obj;
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
     int start;
     idx = 0;
     if (P.cfg.nearest_init) {
         best = P.cfg.max_dis;
         start = 0;
     } else {
-        best = fabs_(signed_distance<KIND>(P, P.objm[0], p));
+        const ObjM o = tab[0];
+        best = fabs_(signed_distance<KIND>(P, o, p));
         start = 1;
     }
     if (NOBJ > 0) {
 #pragma unroll
         for (int i = 0; i < NOBJ; i++) {
             if (i >= start) {
-                float d = fabs_(signed_distance<KIND>(P, P.objm[i], p));
+                const ObjM o = tab[i];
+                float d = fabs_(signed_distance<KIND>(P, o, p));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i : idx;
@@ -143,7 +165,8 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
         }
     } else {
         for (int i = start; i < n; i++) {
-            float d = fabs_(signed_distance<KIND>(P, P.objm[i], p));
+            const ObjM o = tab[i];
+            float d = fabs_(signed_distance<KIND>(P, o, p));
             bool lt = d < best;
             best = lt ? d : best;
             idx = lt ? i : idx;
@@ -202,14 +225,25 @@ RT_D void march_step(const Params& P, Lane& L) {
         // fallback branch: s -= w*s; t += s; w = a + b*w; continue
         float s_fb = L.s - L.w * L.s;
         float w_fb = P.cfg.omega_fb_a + P.cfg.omega_fb_b * L.w;
-        // normal branch
-        float err = dist / L.t;
+        // normal branch: err = d / t; hit = err < PIXEL_RADIUS.  The correctly rounded quotient
+        // is only needed when d is within 2^-20 (relative) of t*eps; otherwise the comparison is
+        // decided by the product (monotone rounding), which saves the 11-instruction divide on
+        // practically every step.  Wave-uniform branch: taken if ANY lane is in the band.
+        float te = L.t * P.cfg.hit_eps;
+        bool sure_hit = dist < te * 0.99999905f;
+        bool sure_miss = dist > te * 1.00000095f;
+        bool unsure = !(sure_hit || sure_miss) || !(L.t > 0.0f);
+        bool hit_n = sure_hit;
+        if (__any(unsure)) {
+            float err = dist / L.t;
+            hit_n = err < P.cfg.hit_eps;
+        }
         float s_nm = L.w * dist;
         float s_new = fb ? s_fb : s_nm;
         L.s = s_new;
         L.t += s_new;
         L.w = fb ? w_fb : L.w;
-        hit = !fb && (err < P.cfg.hit_eps);
+        hit = !fb && hit_n;
         done = !fb && (hit || L.t > P.cfg.max_dis);
     }
     done = done || (L.steps_left == 0);

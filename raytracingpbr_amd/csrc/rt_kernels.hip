@@ -385,6 +385,19 @@ __global__ void math_probe(int op, const float* a, const float* b, float* out, f
     if (out2) out2[i] = r2;
 }
 
+// test hook: custom correctly rounded sqrt_ vs the compiler's IEEE sqrt for every bit pattern
+// in [0, 2^95) (0x6F000000 patterns); counts mismatches.
+__global__ void sqrt_exhaustive(unsigned long long* mismatches) {
+    const uint32_t limit = 0x6F000000u;
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < limit; b += (uint64_t)gridDim.x * blockDim.x) {
+        float x = __builtin_bit_cast(float, (uint32_t)b);
+        float a = sqrt_(x), r = sqrt_ieee_(x);
+        if (__builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, r)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // ---- launchers used by rt_capi.hip -------------------------------------------------------
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st) {
     if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
@@ -424,6 +437,9 @@ void launch_pack(const Params& P, float4* dst, hipStream_t st) {
 void launch_unpack(const Params& P, const float4* src, hipStream_t st) {
     int grid = (P.np + 255) / 256;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3(grid), dim3(256), 0, st, P, src);
+}
+void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st) {
+    hipLaunchKernelGGL(sqrt_exhaustive, dim3(256 * 16), dim3(256), 0, st, mismatches);
 }
 void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st) {
     int grid = (n + 255) / 256;

@@ -37,10 +37,32 @@ RT_HD vec3 operator*(vec3 a, vec3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z
 RT_HD vec3 operator*(vec3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 RT_HD vec3 operator-(vec3 a) { return mk(-a.x, -a.y, -a.z); }
 RT_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RT_HD float sqrt_(float x);
 // a + s*b, fused per component
 RT_HD vec3 fma3(float s, vec3 b, vec3 a) { return mk(fma_(s, b.x, a.x), fma_(s, b.y, a.y), fma_(s, b.z, a.z)); }
 RT_HD float dot(vec3 a, vec3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-RT_HD float sqrt_(float x) { return __builtin_sqrtf(x); }
+// Correctly rounded sqrt.  Host: libm/IEEE.  Device: v_sqrt_f32 (<= 1 ulp) + the two-candidate
+// fma correction LLVM uses for its own IEEE lowering, but with an UNCONDITIONAL exact
+// power-of-two pre/post scaling (2^32 / 2^-16) instead of the compare+select denormal and
+// zero/inf handling: 11 instructions instead of ~17.  Valid for 0 <= x < 2^95 (every length
+// on this path; distances are < MAX_DIS = 2000).  tests/test_gpu_parity.py checks it against
+// the compiler's IEEE sqrt for ALL 2^31 non-negative bit patterns below 2^95.
+RT_HD float sqrt_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float xs = x * 4294967296.0f;
+    float y = __builtin_amdgcn_sqrtf(xs);
+    float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    float rm = __builtin_fmaf(-ym, y, xs);
+    float rp = __builtin_fmaf(-yp, y, xs);
+    y = (0.0f >= rm) ? ym : y;
+    y = (0.0f < rp) ? yp : y;
+    return y * 1.52587890625e-05f;
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+RT_HD float sqrt_ieee_(float x) { return __builtin_sqrtf(x); }
 RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
 RT_HD vec3 normalize(vec3 a) {
     float inv = 1.0f / sqrt_(dot(a, a));

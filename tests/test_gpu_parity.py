@@ -88,10 +88,23 @@ def test_exact_math_functions_match_oracle_bitwise():
     assert all(a[i] == lib.rto_test_asin(float(v)) for i, v in enumerate(x))
     # correctly rounded sqrt and divide on the device == numpy float32 (IEEE)
     x = np.abs(rng.normal(size=n).astype(np.float32)) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
-    x[:8] = [0.0, 1e-45, 1e-40, 1.17549435e-38, 1.0, 2.0, 3.0, 1e30]
+    x[:8] = [0.0, 1e-45, 1e-40, 1.17549435e-38, 1.0, 2.0, 3.0, 1e28]      # domain of sqrt_: [0, 2^95)
     assert np.array_equal(bits(gpu(4, x)), bits(np.sqrt(x)))
     num, den = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
     assert np.array_equal(bits(gpu(5, num, den)), bits(num / den))
+    g.close()
+
+
+def test_device_sqrt_is_correctly_rounded_exhaustively():
+    """The kernels use a slimmed correctly-rounded sqrt (rt_math.hpp sqrt_); compare it with
+    the compiler's IEEE sqrt for every float bit pattern in [0, 2^95) on the device."""
+    api = hip_api()
+    f = api.lib.rtpbr_test_sqrt_exhaustive
+    f.restype, f.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    g = Renderer(cornell_box("v3"), Config.cornell_v3(16, 16))
+    bad = C.c_ulonglong(123)
+    assert f(g._ctx, C.byref(bad)) == 0
+    assert bad.value == 0
     g.close()
 
 
@@ -179,7 +192,7 @@ def test_error_channel():
     with pytest.raises(RtpbrError) as e:
         api.call("sample", ctx, 1)                       # nothing configured yet
     assert e.value.code == -4
-    bad = Config.cornell_v3(0, 16)
+    bad = Config.cornell_v3(16, 16).copy(width=0)
     with pytest.raises(RtpbrError):
         api.call("set_config", ctx, C.byref(bad))
     with pytest.raises(RtpbrError):
