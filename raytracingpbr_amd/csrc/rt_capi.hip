@@ -71,7 +71,7 @@ struct rtpbr_ctx {
     unsigned long long deposits_host = 0;
     // options
     long long staging_bytes = 2LL << 30;
-    int wait_lanes = 16;
+    int wait_lanes = 24;
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
     std::vector<hipEvent_t> ev;
