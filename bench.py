@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--wait-lanes", type=int, default=0)
+    ap.add_argument("--scheduler", type=int, default=-1, help="0 = in-register refill, 1 = LDS ray pool (library default)")
+    ap.add_argument("--shade-lanes", type=int, default=0)
+    ap.add_argument("--swap-lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -105,6 +108,12 @@ def main():
     r = Renderer(sc, cfg, device=local_rank)
     if a.wait_lanes:
         r.set_option("wait_lanes", a.wait_lanes)
+    if a.scheduler >= 0:
+        r.set_option("scheduler", a.scheduler)
+    if a.shade_lanes:
+        r.set_option("shade_lanes", a.shade_lanes)
+    if a.swap_lanes:
+        r.set_option("swap_lanes", a.swap_lanes)
     dev = torch.device("cuda", local_rank)
     tg = TileGather(r, rank, world, device=dev) if world > 1 else None
 

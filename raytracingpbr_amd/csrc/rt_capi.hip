@@ -23,7 +23,7 @@ void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
 void launch_unpack(const Params& P, const float4* src, hipStream_t st);
 void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st);
-int trace_blocks_per_cu(int kind, int n_obj);
+int trace_blocks_per_cu(int kind, int n_obj, int scheduler);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 }  // namespace rt
 
@@ -72,6 +72,9 @@ struct rtpbr_ctx {
     // options
     long long staging_bytes = 2LL << 30;
     int wait_lanes = 24;
+    int shade_lanes = 56;
+    int swap_lanes = 8;
+    int scheduler = 1;
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
     std::vector<hipEvent_t> ev;
@@ -348,7 +351,7 @@ static hipEvent_t next_event(rtpbr_ctx* c) {
 }
 
 static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
-    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj);
+    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->scheduler);
     if (per_cu <= 0) per_cu = 2;
     if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
     long long grid = (long long)per_cu * c->n_cu;
@@ -374,6 +377,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.work_counter = c->work_counter;
     P.counters = c->counters;
     P.wait_lanes = c->wait_lanes;
+    P.shade_lanes = c->shade_lanes;
+    P.swap_lanes = c->swap_lanes;
+    P.scheduler = c->scheduler;
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
@@ -576,6 +582,15 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "wait_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "wait_lanes must be 1..64");
         c->wait_lanes = (int)value;
+    } else if (!strcmp(key, "shade_lanes")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
+        c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "swap_lanes")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 1..64");
+        c->swap_lanes = (int)value;
+    } else if (!strcmp(key, "scheduler")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "scheduler must be 0 or 1");
+        c->scheduler = (int)value;
     } else if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(RTPBR_EINVAL, "waves_per_cu must be 0..32");
         c->waves_per_cu = (int)value;

@@ -153,14 +153,23 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
         start = 1;
     }
     if (NOBJ > 0) {
+        // two objects per iteration: both 64-byte constant blocks are requested before either is
+        // used, so the scalar-load latency of object i+1 hides behind the arithmetic of object i
 #pragma unroll
-        for (int i = 0; i < NOBJ; i++) {
+        for (int i = 0; i < NOBJ; i += 2) {
+            const ObjM oa = tab[i];
+            const ObjM ob = tab[i + 1 < NOBJ ? i + 1 : i];
             if (i >= start) {
-                const ObjM o = tab[i];
-                float d = fabs_(signed_distance<KIND>(P, o, p));
+                float d = fabs_(signed_distance<KIND>(P, oa, p));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i : idx;
+            }
+            if (i + 1 < NOBJ) {
+                float d = fabs_(signed_distance<KIND>(P, ob, p));
+                bool lt = d < best;
+                best = lt ? d : best;
+                idx = lt ? i + 1 : idx;
             }
         }
     } else {

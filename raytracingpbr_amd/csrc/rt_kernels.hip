@@ -59,6 +59,122 @@ RT_D void stage_objects(const Params& P, ObjFull* lds_obj) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Pieces of the bounce loop shared by both schedulers (cornell_box_v3/pathtracer.py:81-106).
+struct PathRay {
+    vec3 o, d, col;
+    float t_eval;      // record.position = o + t_eval*d
+    int idx;           // record.object
+    int bounce;        // i of "for i in range(MAX_RAYTRACE)"
+    uint32_t key, cnt; // RNG stream
+    uint32_t item;     // work item = q*K + k
+};
+
+// after a hit: surface interaction, emission / stop test, next-bounce roulette (:84-89,:97-104).
+// returns true if the path continues with another raycast.
+template <int KIND>
+RT_D bool shade_hit(const Params& P, const ObjFull* lds_obj, PathRay& R) {
+    const ObjFull o = lds_obj[R.idx];
+    vec3 pos = fma3(R.t_eval, R.d, R.o);
+    surface_interaction<KIND>(P, o, pos, R.o, R.d, R.col, R.key, R.cnt);
+    float intensity = brightness(R.col);
+    R.col = R.col * mk(o.emission[0], o.emission[1], o.emission[2]);
+    float visible = brightness(R.col);
+    bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
+    if (stop) return false;
+    R.bounce++;
+    if (R.bounce >= P.cfg.max_raytrace) return false;  // falls out of the loop keeping the throughput (G4)
+    float inv_pdf = exp_((float)R.bounce / P.cfg.light_quality);
+    float p = 1.0f - 1.0f / inv_pdf;
+    if (rng_next(R.key, R.cnt) < p) {
+        R.col = R.col * p;
+        return false;
+    }
+    return true;
+}
+
+// after a miss (:93-95; sky variants tokyo_ibl.py:352-354, bunny_sdf.py:351-354, bunny_sdf_v2.py:355-360)
+RT_D void shade_miss(const Params& P, PathRay& R, uint32_t& n_sky) {
+    if (P.cfg.sky_kind == RTPBR_SKY_BLACK) {
+        R.col = mk(0, 0, 0);
+    } else if (R.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) {
+        R.col = mk(0, 0, 0);
+    } else if (R.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_WHITE) {
+    } else {
+        R.col = R.col * sky_color(P, R.d);
+        n_sky++;
+    }
+}
+
+RT_D void write_sample(const Params& P, uint32_t item, vec3 col, float w) {
+    uint32_t q = item / (uint32_t)P.K;
+    uint32_t k = item - q * (uint32_t)P.K;
+    P.stage[(size_t)k * (size_t)P.np + q] = make_float4(col.x, col.y, col.z, w);
+}
+
+// renderer.py:32-35: jitter, get_ray, color = 1, then roulette at i = 0 (p = 0, the draw is consumed).
+// returns 1 = ray ready to march, 0 = finished already, -1 = padding pixel of an edge tile (nothing to trace)
+RT_D int start_item(const Params& P, PathRay& R) {
+    uint32_t q = R.item / (uint32_t)P.K;
+    uint32_t k = R.item - q * (uint32_t)P.K;
+    int px, py;
+    if (!pixel_of(P, q, px, py)) return -1;
+    R.key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, P.sample_base + k);
+    R.cnt = 0;
+    gen_ray(P, px, py, R.key, R.cnt, R.o, R.d);
+    R.col = mk(1, 1, 1);
+    R.bounce = 0;
+    float inv_pdf = exp_(0.0f / P.cfg.light_quality);
+    float p = 1.0f - 1.0f / inv_pdf;
+    if (rng_next(R.key, R.cnt) < p) {
+        R.col = R.col * p;
+        return 0;
+    }
+    return 1;
+}
+
+// Wave-uniform work range; items are claimed in chunks from one global atomic.
+struct WorkRange {
+    uint32_t next, end;
+    bool drained;
+};
+
+// Hand fresh work items to the lanes with `want` set: ballot + mbcnt prefix rank into the wave's
+// range (wave-uniform control flow).  Returns true for the lanes that received an item.
+RT_D bool claim_items(const Params& P, WorkRange& wr, bool want, int lane, uint32_t& item) {
+    const unsigned long long m = __ballot(want);
+    int need = __popcll(m);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    int assigned = 0;
+    bool got = false;
+    while (need > 0) {
+        if (wr.next == wr.end) {
+            if (wr.drained) break;
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(P.work_counter, P.chunk);
+            start = __builtin_amdgcn_readfirstlane(start);
+            if (start >= P.total_items) {
+                wr.drained = true;
+                break;
+            }
+            wr.next = start;
+            uint32_t e = start + P.chunk;
+            wr.end = e < P.total_items ? e : P.total_items;
+        }
+        int avail = (int)(wr.end - wr.next);
+        int take = need < avail ? need : avail;
+        if (want && !got && rank >= assigned && rank < assigned + take) {
+            item = wr.next + (uint32_t)(rank - assigned);
+            got = true;
+        }
+        wr.next += (uint32_t)take;
+        assigned += take;
+        need -= take;
+    }
+    return got;
+}
+
+// -------------------------------------------------------------------------------------------
+// Scheduler 0: in-register refill (no LDS ray pool).
 template <int KIND, int NOBJ>
 __global__ void __launch_bounds__(256) trace_paths(const Params P) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
@@ -68,150 +184,263 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
     Lane L;
     L.state = ST_IDLE;
     L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
-    L.o = L.d = L.col = mk(0, 0, 0);
+    L.o = L.d = mk(0, 0, 0);
     L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
     L.idx = 0;
     L.steps_left = 0;
-    L.bounce = 0;
-    L.key = L.cnt = L.item = 0;
+    PathRay R;
+    R.o = R.d = R.col = mk(0, 0, 0);
+    R.t_eval = 0.0f;
+    R.idx = R.bounce = 0;
+    R.key = R.cnt = R.item = 0;
     uint32_t n_samples = 0;
-
-    // wave-uniform work range
-    uint32_t next = 0, end = 0;
-    bool drained = false;
+    WorkRange wr = {0, 0, false};
 
     for (;;) {
         // ================================================================ phase B
         bool finished = false;
         bool alive = false;
         if (L.state == ST_HIT) {
-            // cornell_box_v3/pathtracer.py:97-104
-            const ObjFull o = lds_obj[L.idx];
-            vec3 pos = fma3(L.t_eval, L.d, L.o);
-            surface_interaction<KIND>(P, o, pos, L.o, L.d, L.col, L.key, L.cnt);
+            R.o = L.o; R.d = L.d; R.t_eval = L.t_eval; R.idx = L.idx;
+            alive = shade_hit<KIND>(P, lds_obj, R);
             L.n_hits++;
-            float intensity = brightness(L.col);
-            L.col = L.col * mk(o.emission[0], o.emission[1], o.emission[2]);
-            float visible = brightness(L.col);
-            bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
-            if (stop) {
-                finished = true;
-            } else {
-                L.bounce++;
-                if (L.bounce >= P.cfg.max_raytrace) {
-                    finished = true;  // falls out of the loop keeping the throughput (G4)
-                } else {
-                    // russian roulette :84-89
-                    float inv_pdf = exp_((float)L.bounce / P.cfg.light_quality);
-                    float p = 1.0f - 1.0f / inv_pdf;
-                    if (rng_next(L.key, L.cnt) < p) {
-                        L.col = L.col * p;
-                        finished = true;
-                    } else {
-                        alive = true;
-                    }
-                }
-            }
+            finished = !alive;
         } else if (L.state == ST_MISS) {
-            // :93-95 and the sky variants (tokyo_ibl.py:352-354, bunny_sdf.py:351-354, bunny_sdf_v2.py:355-360)
-            if (P.cfg.sky_kind == RTPBR_SKY_BLACK) {
-                L.col = mk(0, 0, 0);
-            } else if (L.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) {
-                L.col = mk(0, 0, 0);
-            } else if (L.bounce == 0 && P.cfg.primary_miss == RTPBR_PRIMARY_WHITE) {
-            } else {
-                L.col = L.col * sky_color(P, L.d);
-                L.n_sky++;
-            }
+            R.d = L.d;
+            shade_miss(P, R, L.n_sky);
             finished = true;
         }
         if (finished) {
-            uint32_t q = L.item / (uint32_t)P.K;
-            uint32_t k = L.item - q * (uint32_t)P.K;
-            P.stage[(size_t)k * (size_t)P.np + q] = make_float4(L.col.x, L.col.y, L.col.z, 1.0f);
+            write_sample(P, R.item, R.col, 1.0f);
             n_samples++;
             L.state = ST_IDLE;
         }
-
-        // ---- refill idle lanes with fresh pixel-samples (wave-uniform control flow)
+        // ---- refill idle lanes with fresh pixel-samples
         {
-            const unsigned long long idle = __ballot(L.state == ST_IDLE);
-            int need = __popcll(idle);
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
-            int assigned = 0;
-            bool got = false;
-            while (need > 0) {
-                if (next == end) {
-                    if (drained) break;
-                    uint32_t start = 0;
-                    if (lane == 0) start = atomicAdd(P.work_counter, P.chunk);
-                    start = __builtin_amdgcn_readfirstlane(start);
-                    if (start >= P.total_items) {
-                        drained = true;
-                        break;
-                    }
-                    next = start;
-                    uint32_t e = start + P.chunk;
-                    end = e < P.total_items ? e : P.total_items;
-                }
-                int avail = (int)(end - next);
-                int take = need < avail ? need : avail;
-                if (L.state == ST_IDLE && !got && rank >= assigned && rank < assigned + take) {
-                    L.item = next + (uint32_t)(rank - assigned);
-                    got = true;
-                }
-                next += (uint32_t)take;
-                assigned += take;
-                need -= take;
-            }
+            bool got = claim_items(P, wr, L.state == ST_IDLE, lane, R.item);
             if (L.state == ST_IDLE) {
                 if (got) {
-                    uint32_t q = L.item / (uint32_t)P.K;
-                    uint32_t k = L.item - q * (uint32_t)P.K;
-                    int px, py;
-                    if (pixel_of(P, q, px, py)) {
-                        // renderer.py:32-35: jitter, get_ray, color = 1; then RR at i = 0 (p = 0, draw consumed)
-                        L.key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, P.sample_base + k);
-                        L.cnt = 0;
-                        gen_ray(P, px, py, L.key, L.cnt, L.o, L.d);
-                        L.col = mk(1, 1, 1);
-                        L.bounce = 0;
-                        float inv_pdf = exp_(0.0f / P.cfg.light_quality);
-                        float p = 1.0f - 1.0f / inv_pdf;
-                        if (rng_next(L.key, L.cnt) < p) {
-                            L.col = L.col * p;
-                            P.stage[(size_t)k * (size_t)P.np + q] = make_float4(L.col.x, L.col.y, L.col.z, 1.0f);
-                            n_samples++;
-                        } else {
-                            alive = true;
-                        }
-                    } else {
-                        // padding pixel of an edge tile: nothing to trace, stays idle until the next refill
-                        P.stage[(size_t)k * (size_t)P.np + q] = make_float4(0, 0, 0, 0);
-                    }
-                } else if (drained) {
+                    int r = start_item(P, R);
+                    if (r == 1) alive = true;
+                    else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
+                    else write_sample(P, R.item, mk(0, 0, 0), 0.0f);   // padding pixel: stays idle until the next refill
+                } else if (wr.drained) {
                     L.state = ST_EXHAUSTED;
                 }
             }
         }
-        if (alive) march_init(P, L);
+        if (alive) {
+            L.o = R.o; L.d = R.d;
+            march_init(P, L);
+        }
 
         // ================================================================ phase A
         unsigned long long marching = __ballot(L.state == ST_MARCH);
         if (marching == 0) {
-            // nothing to march: either everything is exhausted, or only idle padding lanes remain
             if (__ballot(L.state != ST_EXHAUSTED) == 0) break;
             continue;
         }
         const int n_active = __popcll(__ballot(L.state != ST_EXHAUSTED));
         int kstar = P.wait_lanes;
         const int cap = n_active >> 2 > 1 ? n_active >> 2 : 1;
-        kstar = (drained && kstar > cap) ? cap : kstar;
+        kstar = (wr.drained && kstar > cap) ? cap : kstar;
         int n_march;
         do {
             if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
             n_march = __popcll(__ballot(L.state == ST_MARCH));
         } while (n_march > 0 && (n_active - n_march) < kstar);
+    }
+    flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, 0);
+}
+
+// -------------------------------------------------------------------------------------------
+// Scheduler 1: per-wave LDS ray pool ("parked rays").  Every wave owns 64 register lanes (the
+// rays being marched) plus 64 LDS slots holding parked rays that are either READY to start a
+// raycast or waiting to be shaded (HIT / MISS).  A lane whose raycast finishes swaps its ray
+// with a READY slot (ballot + mbcnt rank matching through a small LDS table) and keeps marching,
+// so the march loop stays (nearly) full; shading runs on the SLOTS (lane s <-> slot s) only when
+// >= shade_lanes of them wait, so it runs on (nearly) full waves too.  Slots freed by finished
+// samples are refilled with fresh pixel-samples.  Wave-private: no cross-wave synchronisation.
+enum { SL_EMPTY = 0, SL_READY = 1, SL_HIT = 2, SL_MISS = 3 };
+enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
+
+template <int KIND, int NOBJ>
+__global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
+    __shared__ ObjFull lds_obj[MAX_OBJ];
+    __shared__ uint32_t pool_all[4][F_COUNT][64];
+    __shared__ uint32_t sstate_all[4][64];
+    __shared__ uint32_t tbl_all[4][64];
+    stage_objects(P, lds_obj);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t (*pool)[64] = pool_all[wave];
+    uint32_t* sstate = sstate_all[wave];
+    uint32_t* tbl = tbl_all[wave];
+    sstate[lane] = SL_EMPTY;
+
+    Lane L;
+    L.state = ST_IDLE;   // ST_IDLE = no ray, ST_MARCH, ST_HIT / ST_MISS = raycast done, ray still in registers
+    L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
+    L.o = L.d = mk(0, 0, 0);
+    L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
+    L.idx = 0;
+    L.steps_left = 0;
+    // the marching ray's bookkeeping (travels with the ray through the pool)
+    vec3 a_col = mk(0, 0, 0);
+    int a_bounce = 0;
+    uint32_t a_key = 0, a_cnt = 0, a_item = 0;
+    uint32_t n_samples = 0;
+    WorkRange wr = {0, 0, false};
+    unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
+    const int T = P.shade_lanes;
+    const int m_swap = P.swap_lanes;
+
+    auto f2u = [](float x) { return __builtin_bit_cast(uint32_t, x); };
+    auto u2f = [](uint32_t x) { return __builtin_bit_cast(float, x); };
+
+    for (;;) {
+        // ================================================================ phase B: shade / refill the slots
+        {
+            const int n_shade = __popcll(m_shade);
+            const int n_ready = __popcll(m_ready);
+            const int n_free = 64 - n_shade - n_ready;
+            const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && !wr.drained)));
+            if (run_b) {
+                uint32_t st = sstate[lane];
+                PathRay R;
+                R.o = R.d = R.col = mk(0, 0, 0);
+                R.t_eval = 0.0f;
+                R.idx = R.bounce = 0;
+                R.key = R.cnt = R.item = 0;
+                bool alive = false;
+                if (st == SL_HIT || st == SL_MISS) {
+                    R.o = mk(u2f(pool[F_OX][lane]), u2f(pool[F_OY][lane]), u2f(pool[F_OZ][lane]));
+                    R.d = mk(u2f(pool[F_DX][lane]), u2f(pool[F_DY][lane]), u2f(pool[F_DZ][lane]));
+                    R.col = mk(u2f(pool[F_CR][lane]), u2f(pool[F_CG][lane]), u2f(pool[F_CB][lane]));
+                    R.t_eval = u2f(pool[F_TEVAL][lane]);
+                    R.idx = (int)pool[F_IDX][lane];
+                    R.bounce = (int)pool[F_BOUNCE][lane];
+                    R.key = pool[F_KEY][lane];
+                    R.cnt = pool[F_CNT][lane];
+                    R.item = pool[F_ITEM][lane];
+                    if (st == SL_HIT) {
+                        alive = shade_hit<KIND>(P, lds_obj, R);
+                        L.n_hits++;
+                    } else {
+                        shade_miss(P, R, L.n_sky);
+                    }
+                    if (!alive) {
+                        write_sample(P, R.item, R.col, 1.0f);
+                        n_samples++;
+                    }
+                    st = SL_EMPTY;
+                }
+                // refill free slots with fresh pixel-samples
+                bool got = claim_items(P, wr, st == SL_EMPTY && !alive, lane, R.item);
+                if (got) {
+                    int r = start_item(P, R);
+                    if (r == 1) alive = true;
+                    else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
+                    else write_sample(P, R.item, mk(0, 0, 0), 0.0f);
+                }
+                if (alive) {
+                    pool[F_OX][lane] = f2u(R.o.x); pool[F_OY][lane] = f2u(R.o.y); pool[F_OZ][lane] = f2u(R.o.z);
+                    pool[F_DX][lane] = f2u(R.d.x); pool[F_DY][lane] = f2u(R.d.y); pool[F_DZ][lane] = f2u(R.d.z);
+                    pool[F_CR][lane] = f2u(R.col.x); pool[F_CG][lane] = f2u(R.col.y); pool[F_CB][lane] = f2u(R.col.z);
+                    pool[F_BOUNCE][lane] = (uint32_t)R.bounce;
+                    pool[F_KEY][lane] = R.key;
+                    pool[F_CNT][lane] = R.cnt;
+                    pool[F_ITEM][lane] = R.item;
+                    st = SL_READY;
+                }
+                sstate[lane] = st;
+                m_ready = __ballot(st == SL_READY);
+                m_shade = 0;
+            }
+        }
+
+        // ================================================================ dispatch: swap finished lanes with parked rays
+        {
+            const unsigned long long done = __ballot(L.state == ST_HIT || L.state == ST_MISS);
+            const unsigned long long idle = __ballot(L.state == ST_IDLE);
+            const int n_done = __popcll(done);
+            const int n_ready = __popcll(m_ready);
+            if (n_done > 0 || (idle != 0 && n_ready > 0)) {
+                const unsigned long long m_free = ~(m_ready | m_shade);
+                const int n_free = __popcll(m_free);
+                auto rank_in = [](unsigned long long m) {
+                    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                };
+                // slot side: READY slots first, then free slots, listed by rank
+                const bool s_ready = (m_ready >> lane) & 1ull;
+                const bool s_free = (m_free >> lane) & 1ull;
+                if (s_ready) tbl[rank_in(m_ready)] = (uint32_t)lane;
+                else if (s_free) tbl[n_ready + rank_in(m_free)] = (uint32_t)lane;
+                // lane side: finished lanes first (they carry a ray that must be parked), then idle lanes
+                const bool is_done = (done >> lane) & 1ull;
+                const bool is_idle = (idle >> lane) & 1ull;
+                const int req = is_done ? rank_in(done) : n_done + rank_in(idle);
+                const bool served = (is_done || is_idle) && req < n_ready + n_free;
+                const bool takes = served && req < n_ready;          // gets a READY ray
+                const bool parks = served && is_done;                // leaves its finished ray in the slot
+                uint32_t slot = 0;
+                if (served) slot = tbl[req];
+                vec3 no = L.o, nd = L.d, ncol = a_col;
+                int nbounce = a_bounce;
+                uint32_t nkey = a_key, ncnt = a_cnt, nitem = a_item;
+                if (takes) {
+                    no = mk(u2f(pool[F_OX][slot]), u2f(pool[F_OY][slot]), u2f(pool[F_OZ][slot]));
+                    nd = mk(u2f(pool[F_DX][slot]), u2f(pool[F_DY][slot]), u2f(pool[F_DZ][slot]));
+                    ncol = mk(u2f(pool[F_CR][slot]), u2f(pool[F_CG][slot]), u2f(pool[F_CB][slot]));
+                    nbounce = (int)pool[F_BOUNCE][slot];
+                    nkey = pool[F_KEY][slot];
+                    ncnt = pool[F_CNT][slot];
+                    nitem = pool[F_ITEM][slot];
+                }
+                if (parks) {
+                    pool[F_OX][slot] = f2u(L.o.x); pool[F_OY][slot] = f2u(L.o.y); pool[F_OZ][slot] = f2u(L.o.z);
+                    pool[F_DX][slot] = f2u(L.d.x); pool[F_DY][slot] = f2u(L.d.y); pool[F_DZ][slot] = f2u(L.d.z);
+                    pool[F_CR][slot] = f2u(a_col.x); pool[F_CG][slot] = f2u(a_col.y); pool[F_CB][slot] = f2u(a_col.z);
+                    pool[F_TEVAL][slot] = f2u(L.t_eval);
+                    pool[F_IDX][slot] = (uint32_t)L.idx;
+                    pool[F_BOUNCE][slot] = (uint32_t)a_bounce;
+                    pool[F_KEY][slot] = a_key;
+                    pool[F_CNT][slot] = a_cnt;
+                    pool[F_ITEM][slot] = a_item;
+                    sstate[slot] = L.state == ST_HIT ? SL_HIT : SL_MISS;
+                } else if (takes) {
+                    sstate[slot] = SL_EMPTY;
+                }
+                if (parks) L.state = ST_IDLE;
+                if (takes) {
+                    L.o = no; L.d = nd; a_col = ncol; a_bounce = nbounce; a_key = nkey; a_cnt = ncnt; a_item = nitem;
+                    march_init(P, L);
+                }
+                const uint32_t st = sstate[lane];
+                m_ready = __ballot(st == SL_READY);
+                m_shade = __ballot(st == SL_HIT || st == SL_MISS);
+            }
+        }
+
+        // ================================================================ phase A: march
+        {
+            int n_march = __popcll(__ballot(L.state == ST_MARCH));
+            if (n_march == 0) {
+                const bool any_ray = __ballot(L.state != ST_IDLE) != 0;
+                if (!any_ray && m_ready == 0 && m_shade == 0 && wr.drained) break;
+                continue;
+            }
+            const int n_ready = __popcll(m_ready);
+            int n_done;
+            do {
+                if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+                n_march = __popcll(__ballot(L.state == ST_MARCH));
+                n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
+                // keep marching until enough lanes want a swap; with no READY ray parked, finished lanes
+                // can only be parked, so wait for more of them (bounded by the march lanes running out)
+            } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+        }
     }
     flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, 0);
 }
@@ -400,13 +629,25 @@ __global__ void sqrt_exhaustive(unsigned long long* mismatches) {
 
 // ---- launchers used by rt_capi.hip -------------------------------------------------------
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st) {
+    if (P.scheduler == 1) {
+        if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths_pool<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
+        else if (kind == KIND_BOXES) hipLaunchKernelGGL((trace_paths_pool<KIND_BOXES, 0>), dim3(grid), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((trace_paths_pool<KIND_GENERIC, 0>), dim3(grid), dim3(256), 0, st, P);
+        return;
+    }
     if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
     else if (kind == KIND_BOXES) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 0>), dim3(grid), dim3(256), 0, st, P);
     else hipLaunchKernelGGL((trace_paths<KIND_GENERIC, 0>), dim3(grid), dim3(256), 0, st, P);
 }
-int trace_blocks_per_cu(int kind, int n_obj) {
+int trace_blocks_per_cu(int kind, int n_obj, int scheduler) {
     int per_cu = 0;
     hipError_t e;
+    if (scheduler == 1) {
+        if (kind == KIND_BOXES && n_obj == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_BOXES, 8>, 256, 0);
+        else if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_BOXES, 0>, 256, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_GENERIC, 0>, 256, 0);
+        return e == hipSuccess ? per_cu : 0;
+    }
     if (kind == KIND_BOXES && n_obj == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 8>, 256, 0);
     else if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 0>, 256, 0);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_GENERIC, 0>, 256, 0);

@@ -70,7 +70,10 @@ struct Params {
     int32_t np;             // padded local pixel count = n_local_tiles*tile_w*tile_h
     uint32_t total_items;   // np*K
     uint32_t chunk;         // work items claimed per atomic
-    int32_t wait_lanes;     // k*: leave the march phase when this many lanes wait for shading
+    int32_t wait_lanes;     // k*: leave the march phase when this many lanes wait for shading / a swap
+    int32_t shade_lanes;    // pool scheduler: shade when this many parked rays wait
+    int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
+    int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     // pointers
     float4* stage;
     float4* image_buffer;   // T7 (W,H) float4

@@ -115,7 +115,10 @@ def test_schedule_independence():
     ref = Renderer(case.scene, case.cfg)
     ref.sample(12)
     want = bits(ref.image_buffer)
-    for opts in ({"wait_lanes": 1}, {"wait_lanes": 64}, {"wait_lanes": 7, "waves_per_cu": 4},
+    for opts in ({"scheduler": 0, "wait_lanes": 1}, {"scheduler": 0, "wait_lanes": 64},
+                 {"scheduler": 0, "wait_lanes": 7, "waves_per_cu": 4}, {"scheduler": 0},
+                 {"scheduler": 1, "shade_lanes": 1, "swap_lanes": 1}, {"scheduler": 1, "shade_lanes": 64, "swap_lanes": 64},
+                 {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():

@@ -1,0 +1,24 @@
+"""A/B timing of the headline config (timing only; correctness is covered by pytest -m gpu)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracingpbr_amd import Config, Renderer, cornell_box
+from oracle_backend import OracleRenderer
+# quick exactness check
+cfg = Config.cornell_v3(128, 128, seed=0, max_raytrace=8); sc = cornell_box("v3")
+SCHED = int(os.environ.get("SCHED", "0"))
+g = Renderer(sc, cfg); g.set_option("scheduler", SCHED); g.sample(8); o = OracleRenderer(sc, cfg); o.sample(8)
+print("scheduler", SCHED, "bit-exact:", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)), g.counters(), o.counters())
+cfg = Config.cornell_v3(1920, 1080, seed=0, max_raytrace=8)
+sc = cornell_box("v3", aspect=1920 / 1080)
+import itertools
+for wl, sl, sw in itertools.product([int(x) for x in os.environ.get("WL", "24").split(",")], [int(x) for x in os.environ.get("SL", "48").split(",")], [int(x) for x in os.environ.get("SW", "6").split(",")]):
+    g = Renderer(sc, cfg); g.set_option("wait_lanes", wl); g.set_option("scheduler", SCHED); g.set_option("shade_lanes", sl); g.set_option("swap_lanes", sw)
+    g.sample(4); g.sync()
+    best = 1e9
+    for _ in range(3):
+        g.sample(64); tr, tot, n = g.last_sample_ms(); best = min(best, tr)
+    c = g.counters()
+    print(f"sched={SCHED} wait_lanes={wl:2d} shade_lanes={sl:2d} swap_lanes={sw:2d} trace_ms={best:8.2f} Msamples/s={c.samples / best / 1e3:8.1f}", flush=True)
+    g.close()
