@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--shade-lanes", type=int, default=0)
     ap.add_argument("--swap-lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
+    ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -91,11 +93,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     dist = None
+    if a.same_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -115,7 +122,8 @@ def main():
     if a.swap_lanes:
         r.set_option("swap_lanes", a.swap_lanes)
     dev = torch.device("cuda", local_rank)
-    tg = TileGather(r, rank, world, device=dev) if world > 1 else None
+    # nccl gathers device tensors (RCCL over xGMI); the gloo functional mode stages through the host
+    tg = TileGather(r, rank, world, device=dev if a.backend == "nccl" else None) if world > 1 else None
 
     def step():
         r.refresh()
@@ -145,7 +153,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -165,6 +173,17 @@ def main():
         S = c.march_steps / max(c.raycasts, 1)
         flop_per_sample = 110.0 + B * (S * 338.0 + 197.0 + 110.0 + 25.0) + sky_frac * 15.0   # §8(d) Cornell figures
         achieved_tflops = flop_per_sample * samples_per_launch / avg_launch_s / 1e12
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside
+        # this process); only reported when it was measured on this very workload
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            w = tj["workload"]
+            if (w["width"], w["height"], w["spp"], w["bounces"]) == (W, H, SPP, a.bounces) and world == 1 \
+                    and abs(w["spp_per_launch"] - k_per_launch) < 1e-6:
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+        except Exception:
+            pass
         out = {
             "metric": "Msamples/sec (pixels x spp / s), Cornell Box 1920x1080",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -176,7 +195,7 @@ def main():
                        "parallelism": f"tiles{world}" if world > 1 else "single",
                        "raycasts_per_sample": round(B, 3), "march_steps_per_raycast": round(S, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 8), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "trace_paths", "avg_launch_ms": round(avg_launch_s * 1e3, 3),
                          "algorithmic_bytes_per_launch": round(alg_bytes), "launches_timed": launches,
                          "note": "HBM view requested by the metric; the kernel is FP32-VALU bound, see valu"},

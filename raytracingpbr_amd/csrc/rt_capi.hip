@@ -213,7 +213,7 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
     if (int r = set_dev(c)) return r;
     ObjFull full[MAX_OBJ];
     memset(full, 0, sizeof full);
-    bool all_box = true;
+    bool all_box = true, all_bunny = true, any_bunny = false;
     for (int i = 0; i < n; i++) {
         c->obj[i] = objs[i];
         rtpbr_transform& t = c->obj[i].transform;
@@ -236,11 +236,13 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
         memcpy(f.emission, mt.emission, 12);
         f.roughness = mt.roughness; f.metallic = mt.metallic; f.transmission = mt.transmission; f.ior = mt.ior;
         if (m.type != RTPBR_SHAPE_BOX) all_box = false;
+        if (m.type != RTPBR_SHAPE_BUNNY) all_bunny = false;
+        else any_bunny = true;
         if (m.type < RTPBR_SHAPE_NONE || m.type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
     }
     c->n_obj = n;
     c->P.n_obj = n;
-    c->kind = all_box ? KIND_BOXES : KIND_GENERIC;
+    c->kind = all_box ? KIND_BOXES : all_bunny ? KIND_BUNNY : any_bunny ? KIND_MIXED : KIND_GENERIC;
     HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
     c->have_scene = true;

@@ -11,7 +11,9 @@
 
 namespace rt {
 
-enum { KIND_GENERIC = 0, KIND_BOXES = 1 };
+// scene specialisations: GENERIC = analytic primitives (no neural SDF code), BOXES = all boxes
+// (Cornell), BUNNY = all objects are the neural bunny, MIXED = bunny next to analytic primitives
+enum { KIND_GENERIC = 0, KIND_BOXES = 1, KIND_BUNNY = 2, KIND_MIXED = 3 };
 
 // ---------------------------------------------------------------- F23 bunny MLP
 // examples/bunny/bunny_sdf_glass.py:149-203; weight layout: see tools/extract_bunny_weights.py
@@ -75,6 +77,7 @@ RT_D float sd_box(vec3 l, float sx, float sy, float sz, float rho) {
 template <int KIND>
 RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, float sz) {
     if (KIND == KIND_BOXES) return sd_box(l, sx, sy, sz, P.cfg.box_round);
+    if (KIND == KIND_BUNNY) return sd_bunny(P.bunny, l);
     switch (type) {
         case RTPBR_SHAPE_SPHERE:
             return length(l) - sx;
@@ -93,7 +96,8 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
         case RTPBR_SHAPE_PLANE:
             return l.y - sy;
         case RTPBR_SHAPE_BUNNY:
-            return sd_bunny(P.bunny, l);
+            if (KIND == KIND_MIXED) return sd_bunny(P.bunny, l);
+            return P.cfg.max_dis;
         default:
             return P.cfg.max_dis;
     }
@@ -104,7 +108,7 @@ template <int KIND, typename OBJ>
 RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p) {
     vec3 d = p - mk(o.px, o.py, o.pz);
     vec3 l = mulv(o.m, d);
-    if (KIND != KIND_BOXES && o.type == RTPBR_SHAPE_BUNNY) {
+    if (KIND == KIND_BUNNY || (KIND == KIND_MIXED && o.type == RTPBR_SHAPE_BUNNY)) {
         float st = P.anim_s, ct = P.anim_c;
         vec3 r = mk(fma_(st, l.y, ct * l.x), fma_(ct, l.y, -st * l.x), l.z);
         r.z = r.z + 0.1f * st;
@@ -264,6 +268,24 @@ RT_D void march_step(const Params& P, Lane& L) {
 template <int KIND>
 RT_D vec3 calc_normal(const Params& P, const ObjFull& o, vec3 p) {
     float h = P.cfg.normal_h;
+    if (KIND == KIND_BUNNY || KIND == KIND_MIXED) {
+        // same arithmetic as below, but as a rolled loop: one copy of the (large) MLP code instead of four
+        const bool world = P.cfg.normal_space == RTPBR_NORMAL_WORLD;
+        vec3 q = world ? p : to_local<KIND>(P, o, p);
+        vec3 n = mk(0, 0, 0);
+#pragma nounroll
+        for (int i = 0; i < 4; i++) {
+            // tetrahedron offsets (1,-1,-1), (-1,-1,1), (-1,1,-1), (1,1,1)
+            float ex = (i == 0 || i == 3) ? 1.0f : -1.0f;
+            float ey = (i >= 2) ? 1.0f : -1.0f;
+            float ez = (i & 1) ? 1.0f : -1.0f;
+            vec3 e = world ? mk(ex * h, ey * h, ez * h) : mk(ex, ey, ez);
+            float d = world ? signed_distance<KIND>(P, o, q + e) : sdf_local<KIND>(P, o.type, q + e * h, o.sx, o.sy, o.sz);
+            vec3 t = e * d;
+            n = (i == 0 && world) ? t : n + t;
+        }
+        return normalize(n);
+    }
     if (P.cfg.normal_space == RTPBR_NORMAL_WORLD) {
         vec3 e0 = mk(h, -h, -h), e1 = mk(-h, -h, h), e2 = mk(-h, h, -h), e3 = mk(h, h, h);
         float d0 = signed_distance<KIND>(P, o, p + e0);

@@ -628,29 +628,26 @@ __global__ void sqrt_exhaustive(unsigned long long* mismatches) {
 }
 
 // ---- launchers used by rt_capi.hip -------------------------------------------------------
+#define RT_DISPATCH_KIND(KERNEL, ...)                                                       \
+    do {                                                                                    \
+        if (kind == KIND_BOXES && P.n_obj == 8) { auto k = KERNEL<KIND_BOXES, 8>; __VA_ARGS__; }  \
+        else if (kind == KIND_BOXES) { auto k = KERNEL<KIND_BOXES, 0>; __VA_ARGS__; }        \
+        else if (kind == KIND_BUNNY) { auto k = KERNEL<KIND_BUNNY, 0>; __VA_ARGS__; }        \
+        else if (kind == KIND_MIXED) { auto k = KERNEL<KIND_MIXED, 0>; __VA_ARGS__; }        \
+        else { auto k = KERNEL<KIND_GENERIC, 0>; __VA_ARGS__; }                              \
+    } while (0)
+
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st) {
-    if (P.scheduler == 1) {
-        if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths_pool<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
-        else if (kind == KIND_BOXES) hipLaunchKernelGGL((trace_paths_pool<KIND_BOXES, 0>), dim3(grid), dim3(256), 0, st, P);
-        else hipLaunchKernelGGL((trace_paths_pool<KIND_GENERIC, 0>), dim3(grid), dim3(256), 0, st, P);
-        return;
-    }
-    if (kind == KIND_BOXES && P.n_obj == 8) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 8>), dim3(grid), dim3(256), 0, st, P);
-    else if (kind == KIND_BOXES) hipLaunchKernelGGL((trace_paths<KIND_BOXES, 0>), dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((trace_paths<KIND_GENERIC, 0>), dim3(grid), dim3(256), 0, st, P);
+    if (P.scheduler == 1) RT_DISPATCH_KIND(trace_paths_pool, hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, P));
+    else RT_DISPATCH_KIND(trace_paths, hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, P));
 }
 int trace_blocks_per_cu(int kind, int n_obj, int scheduler) {
     int per_cu = 0;
-    hipError_t e;
-    if (scheduler == 1) {
-        if (kind == KIND_BOXES && n_obj == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_BOXES, 8>, 256, 0);
-        else if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_BOXES, 0>, 256, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths_pool<KIND_GENERIC, 0>, 256, 0);
-        return e == hipSuccess ? per_cu : 0;
-    }
-    if (kind == KIND_BOXES && n_obj == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 8>, 256, 0);
-    else if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_BOXES, 0>, 256, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trace_paths<KIND_GENERIC, 0>, 256, 0);
+    hipError_t e = hipSuccess;
+    Params P;
+    P.n_obj = n_obj;
+    if (scheduler == 1) RT_DISPATCH_KIND(trace_paths_pool, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
+    else RT_DISPATCH_KIND(trace_paths, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     return e == hipSuccess ? per_cu : 0;
 }
 void launch_accumulate(const Params& P, hipStream_t st) {
@@ -660,6 +657,8 @@ void launch_accumulate(const Params& P, hipStream_t st) {
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st) {
     int grid = (P.np + 255) / 256;
     if (kind == KIND_BOXES) hipLaunchKernelGGL((persistent_steps<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P, steps);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((persistent_steps<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P, steps);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((persistent_steps<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P, steps);
     else hipLaunchKernelGGL((persistent_steps<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
 }
 void launch_refresh(float4* ib, rtpbr_ray* rb, size_t n, hipStream_t st) {
