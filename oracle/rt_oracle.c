@@ -507,47 +507,44 @@ static v3 tone_map(const rtpbr_config* g, const float* b) {
  *   layer 1: 4 blocks x {4 mat4 (row major, 64), bias[4]}     (272)  f1k = sin(sum_j f0j @ M_kj + b)/1.0 + f0k
  *   layer 2: 4 blocks x {4 mat4, bias[4]}                     (272)  f2k = sin(sum_j f1j @ M_kj + b)/1.4 + f1k
  *   output : 4 x vec4 + bias                                   (17)
- * v @ M is the row-vector product: (v@M)_j = sum_i v_i M_ij. */
+ * v @ M is the row-vector product: (v@M)_j = sum_i v_i M_ij.
+ * Sums are evaluated as fma chains and the activations with rto_sin_pi (exactly specified). */
 static float sd_bunny(v3 p) {
     float len = v3_length(p);
     if (len > 1.0f) return len - 0.8f;
     if (!g_bunny_set) return len - 0.8f;
     const float* w = g_bunny;
     float f0[16], f1[16], f2[16];
+    /* layer 0: sin(p.y*wy + p.z*wz - p.x*wx + b), as one fma chain */
     for (int k = 0; k < 4; k++) {
         const float* b = w + k * 16;
         for (int j = 0; j < 4; j++) {
-            float a = p.y * b[j] + p.z * b[4 + j] - p.x * b[8 + j] + b[12 + j];
-            f0[k * 4 + j] = rto_sinf(a);
+            float a = fmaf(p.z, b[4 + j], p.y * b[j]);
+            a = fmaf(-p.x, b[8 + j], a);
+            f0[k * 4 + j] = rto_sin_pi(a + b[12 + j]);
         }
     }
+    /* layers 1, 2: out_kj = sin(sum_m sum_i v_mi * M_m[i][j] + bias) [/1.4] + in_kj; the 16-term
+     * sum is one fma chain in (m, i) order */
     const float* src = f0; float* dst = f1;
     for (int layer = 0; layer < 2; layer++) {
         const float* lw = w + 64 + layer * 272;
-        float div = layer == 0 ? 1.0f : 1.4f;
         for (int k = 0; k < 4; k++) {
             const float* bw = lw + k * 68;
             for (int j = 0; j < 4; j++) {
-                float acc = 0.0f;
-                for (int m = 0; m < 4; m++) {
-                    const float* M = bw + m * 16;
-                    const float* v = src + m * 4;
-                    float t = v[0] * M[0 * 4 + j] + v[1] * M[1 * 4 + j] + v[2] * M[2 * 4 + j] + v[3] * M[3 * 4 + j];
-                    acc = (m == 0) ? t : acc + t;
-                }
-                acc = acc + bw[64 + j];
-                dst[k * 4 + j] = rto_sinf(acc) / div + src[k * 4 + j];
+                float acc = src[0] * bw[j];
+                for (int t = 1; t < 16; t++) acc = fmaf(src[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
+                float sn = rto_sin_pi(acc + bw[64 + j]);
+                if (layer == 1) sn = sn / 1.4f;
+                dst[k * 4 + j] = sn + src[k * 4 + j];
             }
         }
         src = f1; dst = f2;
     }
+    /* output: dot(f2, ow) - 0.16 */
     const float* ow = w + 64 + 544;
-    float sd = 0.0f;
-    for (int k = 0; k < 4; k++) {
-        const float* v = f2 + k * 4;
-        float t = v[0] * ow[k * 4 + 0] + v[1] * ow[k * 4 + 1] + v[2] * ow[k * 4 + 2] + v[3] * ow[k * 4 + 3];
-        sd = (k == 0) ? t : sd + t;
-    }
+    float sd = f2[0] * ow[0];
+    for (int t = 1; t < 16; t++) sd = fmaf(f2[t], ow[t], sd);
     return sd + ow[16];
 }
 
@@ -742,6 +739,7 @@ float rto_test_sdf(int type, const float* p, const float* s, float rho) {
 }
 void rto_test_sincos(float a, float* s, float* c) { rto_sincosf(a, s, c); }
 float rto_test_exp(float x) { return rto_expf(x); }
+float rto_test_sin_pi(float x) { return rto_sin_pi(x); }
 float rto_test_atan2(float y, float x) { return rto_atan2f(y, x); }
 float rto_test_asin(float x) { return rto_asinf(x); }
 float rto_test_rand(uint32_t seed, uint32_t x, uint32_t y, uint32_t s, uint32_t n) {

@@ -80,6 +80,22 @@ static inline void rto_sincosf(float a, float* s_out, float* c_out) {
 }
 static inline float rto_sinf(float a) { float s, c; rto_sincosf(a, &s, &c); return s; }
 
+/* ---- sin for the neural-SDF activations: reduction by pi (3-term Cody-Waite), one odd
+ * degree-9 minimax polynomial on [-pi/2, pi/2] (max abs error 1.2e-7), sign from the parity of k.
+ * 16 operations instead of 22; used 48 times per bunny SDF evaluation. ---- */
+static inline float rto_sin_pi(float a) {
+    float kf = rintf(a * RTO_INV_PI);
+    int k = (int)kf;
+    float r = fmaf(kf, -3.140625f, a);
+    r = fmaf(kf, -9.67502593994140625e-4f, r);
+    r = fmaf(kf, -1.509957990978376432e-7f, r);
+    float r2 = r * r;
+    float p = fmaf(fmaf(fmaf(2.6073803383042105e-06f, r2, -0.00019809493096545339f), r2, 0.008333046920597553f), r2,
+                   -0.16666658222675323f);
+    float s = fmaf(r * r2, p, r);
+    return (k & 1) ? -s : s;
+}
+
 /* ---- exp: Cephes expf ---- */
 static inline float rto_expf(float x) {
     float kf = rintf(x * 1.44269504088896341f);

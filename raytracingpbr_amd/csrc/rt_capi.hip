@@ -391,14 +391,20 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     c->timed = true;
     HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
     if (c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY) {
-        // n launches of pathtrace() (src/renderer.py:29-30)
-        for (int i = 0; i < n; i++) {
+        // n launches of pathtrace() (src/renderer.py:29-30), each cfg.steps_per_launch bounce-steps.
+        // A pixel's steps are sequential and the RNG is keyed by the absolute step index, so k
+        // launches of s steps equal one launch of k*s steps bit for bit: fuse them (<= 256 steps
+        // per kernel) instead of paying a launch + an 80 B/pixel ray_buffer round trip per step.
+        long long left = (long long)n * c->cfg.steps_per_launch;
+        while (left > 0) {
+            int steps = (int)(left < 256 ? left : 256);
             P.sample_base = c->sample_base;
             hipEvent_t a = next_event(c), b = next_event(c);
             HIP_TRY(hipEventRecord(a, c->stream));
-            launch_persistent(P, c->kind, c->cfg.steps_per_launch, c->stream);
+            launch_persistent(P, c->kind, steps, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
-            c->sample_base += (uint32_t)c->cfg.steps_per_launch;
+            c->sample_base += (uint32_t)steps;
+            left -= steps;
         }
     } else {
         int left = n;

@@ -16,53 +16,61 @@ namespace rt {
 enum { KIND_GENERIC = 0, KIND_BOXES = 1, KIND_BUNNY = 2, KIND_MIXED = 3 };
 
 // ---------------------------------------------------------------- F23 bunny MLP
-// examples/bunny/bunny_sdf_glass.py:149-203; weight layout: see tools/extract_bunny_weights.py
-RT_D float sd_bunny(const float* __restrict__ w, vec3 p) {
+// examples/bunny/bunny_sdf_glass.py:149-203; weight layout: see tools/extract_bunny_weights.py.
+// 3 -> 16 -> 16 -> 16 -> 1 with sine activations and residual adds.  Sums are fma chains in
+// (block, row) order, activations use sin_pi_.  The 625 weights are read at wave-uniform
+// addresses through a constant-address-space pointer (scalar loads -> SGPR operands); the pointer
+// is laundered so the loads are not hoisted out of the march loop (that would spill them).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float* CFloatPtr;
+#else
+typedef const float* CFloatPtr;
+#endif
+
+RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
     float len = length(p);
-    if (len > 1.0f || w == nullptr) return len - 0.8f;
-    float f0[16], f1[16], f2[16];
+    if (len > 1.0f || wg == nullptr) return len - 0.8f;
+    CFloatPtr w = (CFloatPtr)wg;
+    asm volatile("" : "+s"(w));
+    float f0[16], f1[16];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float* b = w + k * 16;
+        CFloatPtr b = w + k * 16;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float a = p.y * b[j] + p.z * b[4 + j] - p.x * b[8 + j] + b[12 + j];
-            f0[k * 4 + j] = sin_(a);
+            float a = fma_(p.z, b[4 + j], p.y * b[j]);
+            a = fma_(-p.x, b[8 + j], a);
+            f0[k * 4 + j] = sin_pi_(a + b[12 + j]);
         }
     }
-#pragma unroll
-    for (int layer = 0; layer < 2; layer++) {
-        const float* lw = w + 64 + layer * 272;
-        const float* src = layer == 0 ? f0 : f1;
-        float* dst = layer == 0 ? f1 : f2;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float* bw = lw + k * 68;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const float* M = bw + m * 16;
-                    const float* v = src + m * 4;
-                    float t = v[0] * M[0 * 4 + j] + v[1] * M[1 * 4 + j] + v[2] * M[2 * 4 + j] + v[3] * M[3 * 4 + j];
-                    acc = (m == 0) ? t : acc + t;
-                }
-                acc = acc + bw[64 + j];
-                float sn = sin_(acc);
-                if (layer == 1) sn = sn / 1.4f;
-                dst[k * 4 + j] = sn + src[k * 4 + j];
-            }
-        }
-    }
-    const float* ow = w + 64 + 544;
-    float sd = 0.0f;
+    // layer 1: f1 = sin(f0 @ W1 + b1) + f0
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const float* v = f2 + k * 4;
-        float t = v[0] * ow[k * 4 + 0] + v[1] * ow[k * 4 + 1] + v[2] * ow[k * 4 + 2] + v[3] * ow[k * 4 + 3];
-        sd = (k == 0) ? t : sd + t;
+        CFloatPtr bw = w + 64 + k * 68;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float acc = f0[0] * bw[j];
+#pragma unroll
+            for (int t = 1; t < 16; t++) acc = fma_(f0[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
+            f1[k * 4 + j] = sin_pi_(acc + bw[64 + j]) + f0[k * 4 + j];
+        }
     }
+    // layer 2 (f2 overwrites f0): f2 = sin(f1 @ W2 + b2) / 1.4 + f1
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        CFloatPtr bw = w + 64 + 272 + k * 68;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float acc = f1[0] * bw[j];
+#pragma unroll
+            for (int t = 1; t < 16; t++) acc = fma_(f1[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
+            f0[k * 4 + j] = sin_pi_(acc + bw[64 + j]) / 1.4f + f1[k * 4 + j];
+        }
+    }
+    CFloatPtr ow = w + 64 + 544;
+    float sd = f0[0] * ow[0];
+#pragma unroll
+    for (int t = 1; t < 16; t++) sd = fma_(f0[t], ow[t], sd);
     return sd + ow[16];
 }
 

@@ -105,10 +105,10 @@ RT_D void shade_miss(const Params& P, PathRay& R, uint32_t& n_sky) {
     }
 }
 
+// Staging layout [q][k] = item-linear: the items a wave has in flight are (nearly) consecutive,
+// so its 16-byte stores fall into the same few cache lines and merge in L2 before they reach HBM.
 RT_D void write_sample(const Params& P, uint32_t item, vec3 col, float w) {
-    uint32_t q = item / (uint32_t)P.K;
-    uint32_t k = item - q * (uint32_t)P.K;
-    P.stage[(size_t)k * (size_t)P.np + q] = make_float4(col.x, col.y, col.z, w);
+    P.stage[item] = make_float4(col.x, col.y, col.z, w);
 }
 
 // renderer.py:32-35: jitter, get_ray, color = 1, then roulette at i = 0 (p = 0, the draw is consumed).
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
     float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
     float4 acc = *dst;
     for (int k = 0; k < P.K; k++) {
-        float4 c = P.stage[(size_t)k * (size_t)P.np + q];
+        float4 c = P.stage[(size_t)q * (size_t)P.K + k];
         acc.x += c.x;
         acc.y += c.y;
         acc.z += c.z;
@@ -607,6 +607,7 @@ __global__ void math_probe(int op, const float* a, const float* b, float* out, f
         case 3: r = asin_(x); break;
         case 4: r = sqrt_(x); break;
         case 5: r = x / y; break;
+        case 7: r = sin_pi_(x); break;
         case 6: { uint32_t n0 = __builtin_bit_cast(uint32_t, y); r = rng_next(__builtin_bit_cast(uint32_t, x), n0); } break;
         default: break;
     }

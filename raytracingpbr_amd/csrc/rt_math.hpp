@@ -109,6 +109,21 @@ RT_HD float sin_(float a) {
     return s;
 }
 
+// sin for the neural-SDF activations: reduction by pi (3-term Cody-Waite) + one odd degree-9
+// minimax polynomial on [-pi/2, pi/2] (max abs error 1.2e-7), sign from the parity of k.
+RT_HD float sin_pi_(float a) {
+    float kf = __builtin_rintf(a * INV_PI);
+    int k = (int)kf;
+    float r = fma_(kf, -3.140625f, a);
+    r = fma_(kf, -9.67502593994140625e-4f, r);
+    r = fma_(kf, -1.509957990978376432e-7f, r);
+    float r2 = r * r;
+    float p = fma_(fma_(fma_(2.6073803383042105e-06f, r2, -0.00019809493096545339f), r2, 0.008333046920597553f), r2,
+                   -0.16666658222675323f);
+    float s = fma_(r * r2, p, r);
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) ^ ((uint32_t)k << 31));
+}
+
 // exp: Cephes expf
 RT_HD float exp_(float x) {
     float kf = __builtin_rintf(x * 1.44269504088896341f);

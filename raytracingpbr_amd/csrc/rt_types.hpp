@@ -7,7 +7,7 @@
 //     consumed as scalar operands and cost no VGPRs and no LDS bandwidth.
 //   ObjFull[n] (HBM -> LDS once per workgroup): transform + material of every object,
 //     gathered PER LANE by hit-object index in the shading phase (T4).
-//   stage (HBM): one float4 per pixel-sample of the current sub-launch, [k][q] (q fastest),
+//   stage (HBM): one float4 per pixel-sample of the current sub-launch, [q][k] (k fastest),
 //     reduced in sample order into image_buffer (T7) by the accumulate kernel.
 #pragma once
 #include <stdint.h>

@@ -77,6 +77,10 @@ def test_exact_math_functions_match_oracle_bitwise():
     for i, v in enumerate(x):
         lib.rto_test_sincos(float(v), C.byref(rs), C.byref(rc))
         assert s[i] == rs.value and c[i] == rc.value, (v, s[i], rs.value)
+    lib.rto_test_sin_pi.restype = C.c_float; lib.rto_test_sin_pi.argtypes = [C.c_float]
+    x = rng.uniform(-40, 40, 4000).astype(np.float32)
+    sp = gpu(7, x)
+    assert all(sp[i] == lib.rto_test_sin_pi(float(v)) for i, v in enumerate(x))
     x = rng.uniform(-8, 8, 3000).astype(np.float32)
     e = gpu(1, x)
     assert all(e[i] == lib.rto_test_exp(float(v)) for i, v in enumerate(x))

@@ -34,6 +34,14 @@ def test_sincos_known_values(oracle_lib):
     assert s.value == 0.0 and c.value == 1.0
 
 
+def test_sin_pi_for_mlp_activations(oracle_lib):
+    f = _f(oracle_lib, "rto_test_sin_pi", C.c_float, [C.c_float])
+    xs = np.concatenate([np.linspace(-40, 40, 8001), [0.0, np.pi / 2, np.pi, -np.pi / 2]]).astype(np.float32)
+    worst = max(abs(f(float(x)) - np.sin(np.float64(x))) for x in xs)
+    assert worst < 4e-7, worst
+    assert f(0.0) == 0.0
+
+
 def test_exp(oracle_lib):
     f = _f(oracle_lib, "rto_test_exp", C.c_float, [C.c_float])
     assert f(0.0) == 1.0

@@ -1,0 +1,45 @@
+"""Time every BASELINE.json config on ONE GPU (the multi-GPU ones as rank 0 of G virtual ranks,
+i.e. the per-GPU share of the tile-partitioned frame).  Throughput only; parity is in tests/."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from raytracingpbr_amd import SHAPE, Config, Renderer, bunny, cornell_box, src_scene
+from raytracingpbr_amd.ibl import load_bunny_weights, synthetic_env
+from raytracingpbr_amd.tiles import default_tile
+
+only = set(sys.argv[1:])
+res = {}
+
+def run(name, sc, cfg, spp, env=None, envexp=1.8, tiles=None, chunk=None, warm=1):
+    if only and name not in only: return
+    r = Renderer(sc, cfg)
+    if env is not None: r.set_env(env, envexp, 2.2)
+    if any(o.type == SHAPE.BUNNY for o in sc.objects): r.set_shape_data(SHAPE.BUNNY, load_bunny_weights())
+    if tiles: r.set_tiles(*tiles)
+    r.sample(warm); r.sync()
+    chunk = chunk or spp
+    tr_tot, tot_tot, samples, c = 0.0, 0.0, 0, None
+    t0 = time.time()
+    for _ in range(spp // chunk):
+        r.sample(chunk); tr, tot, n = r.last_sample_ms(); c = r.counters()
+        tr_tot += tr; tot_tot += tot; samples += c.samples
+    wall = time.time() - t0
+    out = {"samples": samples, "trace_ms": round(tr_tot, 2), "total_ms": round(tot_tot, 2), "wall_s": round(wall, 3),
+           "Msamples_per_s": round(samples / tot_tot / 1e3, 2), "raycasts_per_sample": round(c.raycasts / c.samples, 3),
+           "march_steps_per_raycast": round(c.march_steps / max(c.raycasts, 1), 2), "sky_per_sample": round(c.sky_lookups / c.samples, 3)}
+    res[name] = out
+    print(name, json.dumps(out), flush=True)
+    r.close()
+
+env3k = synthetic_env(3072, 1536, seed=0)
+run("C1_cornell_256x256_16spp_4b", cornell_box("v3"), Config.cornell_v3(256, 256, 0, 4), 16)
+run("C2_cornell_1080p_256spp_8b", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(1920, 1080, 0, 8), 256)
+spp3 = int(os.environ.get("C3_SPP", "16"))
+run(f"C3_bunny_glass_1080p_{spp3}spp_16b(of 1024)", bunny(aspect=16 / 9), Config.bunny_glass(1920, 1080, 0, 16), spp3, env=env3k, warm=1)
+tw, th = default_tile(3840, 2160, 4)
+run("C4_tokyo_ibl_4k_512spp_rank0of4", src_scene(aspect=16 / 9, tokyo=True), Config.tokyo_ibl(3840, 2160, 0, 512), 512, env=env3k, tiles=(tw, th, 0, 4), chunk=64)
+tw, th = default_tile(7680, 4320, 8)
+run("C5_cornell_8k_256spp(of 4096)_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), 256, tiles=(tw, th, 0, 8), chunk=64)
+run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4, chunk=64)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
