@@ -198,12 +198,18 @@ typedef struct rtpbr_config {
     int32_t  frame;
     /* persistent-ray form: bounce-steps per pixel per launch (SAMPLES_PER_PIXEL) */
     int32_t  steps_per_launch;
+    /* self-adaptive sampling (src/config.py:14,17; persistent-ray form only): a pixel is sampled
+     * only while its running mean display-space change diff_pixels exceeds noise_threshold */
+    int32_t  adaptive_sampling;
+    float    noise_threshold;
 } rtpbr_config;
 
 /* ------------------------------------------------------------------ buffers */
 enum { RTPBR_BUF_IMAGE_BUFFER = 0,   /* T7 image_buffer  (W,H,4) f32: (sum r, sum g, sum b, count) */
        RTPBR_BUF_IMAGE_PIXELS = 1,   /* T8 image_pixels  (W,H,3) f32 display colour                */
-       RTPBR_BUF_RAY_BUFFER   = 2 }; /* T6 ray_buffer    (W,H) of rtpbr_ray (persistent-ray form)  */
+       RTPBR_BUF_RAY_BUFFER   = 2,   /* T6 ray_buffer    (W,H) of rtpbr_ray (persistent-ray form)  */
+       RTPBR_BUF_DIFF_BUFFER  = 3,   /* T11 diff_buffer  (W,H,2) f32 (sum of display change, count) src/fileds.py:21 */
+       RTPBR_BUF_DIFF_PIXELS  = 4 }; /* T11 diff_pixels  (W,H) f32                                  src/fileds.py:22 */
 
 enum { RTPBR_ENV_RGB8 = 0,           /* uint8 (W_e,H_e,3), [x][y], y=0 bottom: what ti.tools.imread gives */
        RTPBR_ENV_RGB32F = 1 };       /* float32 (W_e,H_e,3) already preprocessed (T9 as is)               */

@@ -39,6 +39,8 @@ struct rto_ctx {
     float* image_buffer;                  /* T7 */
     float* image_pixels;                  /* T8 */
     rtpbr_ray* ray_buffer;                /* T6 */
+    float* diff_buffer;                   /* T11 (W,H,2) */
+    float* diff_pixels;                   /* T11 (W,H) */
     int tile_w, tile_h, rank, world;
     uint32_t sample_base;                 /* samples (or bounce-steps) done since create */
     rtpbr_counters ctr;
@@ -487,7 +489,7 @@ static v3 aces_fit(v3 c, int trunc) {
 }
 static inline float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static inline v3 v3_clamp01(v3 c) { return v3_make(clamp01(c.x), clamp01(c.y), clamp01(c.z)); }
-static inline v3 v3_pow(v3 c, float e) { return v3_make(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+static inline v3 v3_pow(v3 c, float e) { return v3_make(rto_powf(c.x, e), rto_powf(c.y, e), rto_powf(c.z, e)); }
 
 static v3 tone_map(const rtpbr_config* g, const float* b) {
     v3 c = v3_make(b[0] / b[3], b[1] / b[3], b[2] / b[3]);
@@ -563,7 +565,8 @@ int rto_create(int device, struct rto_ctx** out) {
 }
 int rto_destroy(struct rto_ctx* c) {
     if (!c) return RTPBR_OK;
-    free(c->env); free(c->image_buffer); free(c->image_pixels); free(c->ray_buffer); free(c);
+    free(c->env); free(c->image_buffer); free(c->image_pixels); free(c->ray_buffer);
+    free(c->diff_buffer); free(c->diff_pixels); free(c);
     return RTPBR_OK;
 }
 int rto_set_config(struct rto_ctx* c, const rtpbr_config* cfg) {
@@ -574,11 +577,13 @@ int rto_set_config(struct rto_ctx* c, const rtpbr_config* cfg) {
     c->have_cfg = 1;
     if (realloc_buf) {
         size_t P = (size_t)cfg->width * cfg->height;
-        free(c->image_buffer); free(c->image_pixels); free(c->ray_buffer);
+        free(c->image_buffer); free(c->image_pixels); free(c->ray_buffer); free(c->diff_buffer); free(c->diff_pixels);
         c->image_buffer = (float*)calloc(P * 4, sizeof(float));
         c->image_pixels = (float*)calloc(P * 3, sizeof(float));
         c->ray_buffer = (rtpbr_ray*)calloc(P, sizeof(rtpbr_ray));
-        if (!c->image_buffer || !c->image_pixels || !c->ray_buffer) return fail(RTPBR_ENOMEM, "buffers");
+        c->diff_buffer = (float*)calloc(P * 2, sizeof(float));
+        c->diff_pixels = (float*)calloc(P, sizeof(float));
+        if (!c->image_buffer || !c->image_pixels || !c->ray_buffer || !c->diff_buffer || !c->diff_pixels) return fail(RTPBR_ENOMEM, "buffers");
     }
     return RTPBR_OK;
 }
@@ -615,7 +620,7 @@ int rto_set_env(struct rto_ctx* c, const void* texels, int w, int h, int fmt, fl
     if (fmt == RTPBR_ENV_RGB8) {
         const uint8_t* s = (const uint8_t*)texels;
         float lut[256];
-        for (int i = 0; i < 256; i++) lut[i] = powf(((float)i / 255.0f) * exposure, gamma);
+        for (int i = 0; i < 256; i++) lut[i] = rto_powf(((float)i / 255.0f) * exposure, gamma);
         for (size_t i = 0; i < n; i++) c->env[i] = lut[s[i]];
     } else memcpy(c->env, texels, n * sizeof(float));
     c->env_w = w; c->env_h = h;
@@ -639,6 +644,8 @@ int rto_refresh(struct rto_ctx* c) {
     size_t P = (size_t)c->cfg.width * c->cfg.height;
     memset(c->image_buffer, 0, P * 4 * sizeof(float));
     for (size_t i = 0; i < P; i++) c->ray_buffer[i].depth = 0;
+    if (c->cfg.adaptive_sampling)                              /* src/renderer.py:19-21 */
+        for (size_t i = 0; i < P; i++) { c->diff_buffer[i * 2] = 1.0f; c->diff_buffer[i * 2 + 1] = 1.0f; c->diff_pixels[i] = 1e32f; }
     return RTPBR_OK;
 }
 int rto_set_threads(struct rto_ctx* c, int n) { c->threads = n; return RTPBR_OK; }
@@ -666,6 +673,9 @@ int rto_sample(struct rto_ctx* c, int n) {
             for (int y = 0; y < H; y++) {
                 if (!owns(c, x, y)) continue;
                 if (persistent) {
+                    /* src/pathtracer.py:97-101: adaptive mask, evaluated once per pathtrace() launch;
+                     * diff_pixels only changes in post_process(), so once per call is the same */
+                    if (c->cfg.adaptive_sampling && !(c->diff_pixels[(size_t)x * H + y] > c->cfg.noise_threshold)) continue;
                     for (int s = 0; s < steps; s++) step_persistent(c, &f, x, y, base + (uint32_t)s, &ctr);
                 } else {
                     float* ib = c->image_buffer + ((size_t)x * H + y) * 4;
@@ -693,8 +703,15 @@ int rto_post_process(struct rto_ctx* c) {
     if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "no config");
     size_t P = (size_t)c->cfg.width * c->cfg.height;
     for (size_t i = 0; i < P; i++) {
+        v3 last = v3_make(c->image_pixels[i * 3], c->image_pixels[i * 3 + 1], c->image_pixels[i * 3 + 2]);
         v3 t = tone_map(&c->cfg, c->image_buffer + i * 4);
         c->image_pixels[i * 3 + 0] = t.x; c->image_pixels[i * 3 + 1] = t.y; c->image_pixels[i * 3 + 2] = t.z;
+        if (c->cfg.adaptive_sampling) {                         /* src/postprocessor.py:40-43 */
+            v3 dc = v3_make(fabsf(t.x - last.x), fabsf(t.y - last.y), fabsf(t.z - last.z));
+            c->diff_buffer[i * 2] += brightness(dc);
+            c->diff_buffer[i * 2 + 1] += 1.0f;
+            c->diff_pixels[i] = c->diff_buffer[i * 2] / c->diff_buffer[i * 2 + 1];
+        }
     }
     return RTPBR_OK;
 }
@@ -707,6 +724,8 @@ static int buf_ptr(struct rto_ctx* c, int which, void** p, size_t* n) {
     case RTPBR_BUF_IMAGE_BUFFER: *p = c->image_buffer; *n = P * 16; return 0;
     case RTPBR_BUF_IMAGE_PIXELS: *p = c->image_pixels; *n = P * 12; return 0;
     case RTPBR_BUF_RAY_BUFFER:   *p = c->ray_buffer;   *n = P * sizeof(rtpbr_ray); return 0;
+    case RTPBR_BUF_DIFF_BUFFER:  *p = c->diff_buffer;  *n = P * 8; return 0;
+    case RTPBR_BUF_DIFF_PIXELS:  *p = c->diff_pixels;  *n = P * 4; return 0;
     }
     return fail(RTPBR_EINVAL, "bad buffer id");
 }
@@ -740,6 +759,8 @@ float rto_test_sdf(int type, const float* p, const float* s, float rho) {
 void rto_test_sincos(float a, float* s, float* c) { rto_sincosf(a, s, c); }
 float rto_test_exp(float x) { return rto_expf(x); }
 float rto_test_sin_pi(float x) { return rto_sin_pi(x); }
+float rto_test_log(float x) { return rto_logf(x); }
+float rto_test_pow(float x, float y) { return rto_powf(x, y); }
 float rto_test_atan2(float y, float x) { return rto_atan2f(y, x); }
 float rto_test_asin(float x) { return rto_asinf(x); }
 float rto_test_rand(uint32_t seed, uint32_t x, uint32_t y, uint32_t s, uint32_t n) {

@@ -116,6 +116,40 @@ static inline float rto_expf(float x) {
     return e * sc;
 }
 
+/* ---- log (Cephes logf) and pow(x, y) = exp(y*log(x)) for x >= 0: the tone map's and the env
+ * preprocess's pow(c, gamma) (src/postprocessor.py:17-21).  x < 0 gives NaN like powf. ---- */
+static inline float rto_logf(float x) {
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 16777216.0f; e = -24; }
+    uint32_t b; memcpy(&b, &x, 4);
+    e += (int)((b >> 23) & 0xffu) - 126;
+    b = (b & 0x807fffffu) | 0x3f000000u;
+    float m; memcpy(&m, &b, 4);                       /* m in [0.5, 1) */
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else m = m - 1.0f;
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fmaf(y, m, -1.1514610310e-1f);
+    y = fmaf(y, m, 1.1676998740e-1f);
+    y = fmaf(y, m, -1.2420140846e-1f);
+    y = fmaf(y, m, 1.4249322787e-1f);
+    y = fmaf(y, m, -1.6668057665e-1f);
+    y = fmaf(y, m, 2.0000714765e-1f);
+    y = fmaf(y, m, -2.4999993993e-1f);
+    y = fmaf(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    float fe = (float)e;
+    y = fmaf(-2.12194440e-4f, fe, y);
+    y = fmaf(-0.5f, z, y);
+    z = m + y;
+    return fmaf(0.693359375f, fe, z);
+}
+static inline float rto_powf(float x, float y) {
+    if (x == 0.0f) return 0.0f;
+    if (!(x > 0.0f)) return NAN;
+    return rto_expf(y * rto_logf(x));
+}
+
 /* ---- atan on [0, inf): Cephes atanf ---- */
 static inline float rto_atanf_pos(float x) {
     float y0, z;

@@ -61,6 +61,7 @@ class Config(C.Structure):
         ("tonemap_order", C.c_int32), ("aces_truncated", C.c_int32),
         ("exposure", C.c_float), ("gamma", C.c_float),
         ("frame", C.c_int32), ("steps_per_launch", C.c_int32),
+        ("adaptive_sampling", C.c_int32), ("noise_threshold", C.c_float),
     ]
 
     def copy(self, **kw):
@@ -95,6 +96,7 @@ class Config(C.Structure):
         c.camera_kind = 0
         c.tonemap_order, c.aces_truncated, c.exposure, c.gamma = TONEMAP.GAMMA_ACES_CLAMP, 0, 1.0, 2.2
         c.frame, c.steps_per_launch = 0, 1
+        c.adaptive_sampling, c.noise_threshold = 0, 1e-4          # src/config.py:14,17
         return c
 
     @staticmethod

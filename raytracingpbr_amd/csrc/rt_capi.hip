@@ -18,7 +18,7 @@ namespace rt {
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
 void launch_accumulate(const Params& P, hipStream_t st);
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
-void launch_refresh(float4* ib, rtpbr_ray* rb, size_t n, hipStream_t st);
+void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st);
 void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
 void launch_unpack(const Params& P, const float4* src, hipStream_t st);
@@ -57,6 +57,8 @@ struct rtpbr_ctx {
     float4* image_buffer = nullptr;
     float* image_pixels = nullptr;
     rtpbr_ray* ray_buffer = nullptr;
+    float2* diff_buffer = nullptr;
+    float* diff_pixels = nullptr;
     ObjFull* objfull = nullptr;
     float4* env = nullptr;
     float* bunny = nullptr;
@@ -121,6 +123,8 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->image_buffer);
     (void)hipFree(c->image_pixels);
     (void)hipFree(c->ray_buffer);
+    (void)hipFree(c->diff_buffer);
+    (void)hipFree(c->diff_pixels);
     (void)hipFree(c->objfull);
     (void)hipFree(c->env);
     (void)hipFree(c->bunny);
@@ -172,15 +176,23 @@ extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
         (void)hipFree(c->image_buffer);
         (void)hipFree(c->image_pixels);
         (void)hipFree(c->ray_buffer);
+        (void)hipFree(c->diff_buffer);
+        (void)hipFree(c->diff_pixels);
         c->image_buffer = nullptr;
         c->image_pixels = nullptr;
         c->ray_buffer = nullptr;
+        c->diff_buffer = nullptr;
+        c->diff_pixels = nullptr;
         HIP_TRY(hipMalloc(&c->image_buffer, n * sizeof(float4)));
         HIP_TRY(hipMalloc(&c->image_pixels, n * 3 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->ray_buffer, n * sizeof(rtpbr_ray)));
         HIP_TRY(hipMemsetAsync(c->image_buffer, 0, n * sizeof(float4), c->stream));
         HIP_TRY(hipMemsetAsync(c->image_pixels, 0, n * 3 * sizeof(float), c->stream));
         HIP_TRY(hipMemsetAsync(c->ray_buffer, 0, n * sizeof(rtpbr_ray), c->stream));
+        HIP_TRY(hipMalloc(&c->diff_buffer, n * sizeof(float2)));
+        HIP_TRY(hipMalloc(&c->diff_pixels, n * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(c->diff_buffer, 0, n * sizeof(float2), c->stream));
+        HIP_TRY(hipMemsetAsync(c->diff_pixels, 0, n * sizeof(float), c->stream));
     }
     // bunny animation uniform: t = pi*frame/120 (bunny_sdf_glass.py:214)
     float t = PI * (float)cfg->frame / 120.0f;
@@ -295,7 +307,7 @@ extern "C" int rtpbr_set_env(rtpbr_ctx* c, const void* texels, int w, int h, int
     if (fmt == RTPBR_ENV_RGB8) {
         const uint8_t* s = (const uint8_t*)texels;
         float lut[256];
-        for (int i = 0; i < 256; i++) lut[i] = powf(((float)i / 255.0f) * exposure, gamma);
+        for (int i = 0; i < 256; i++) lut[i] = pow_(((float)i / 255.0f) * exposure, gamma);
         for (size_t i = 0; i < n; i++) host[i] = make_float4(lut[s[i * 3]], lut[s[i * 3 + 1]], lut[s[i * 3 + 2]], 0.0f);
     } else {
         const float* s = (const float*)texels;
@@ -338,7 +350,7 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
     if (int r = set_dev(c)) return r;
     size_t n = (size_t)c->cfg.width * c->cfg.height;
-    launch_refresh(c->image_buffer, c->ray_buffer, n, c->stream);
+    launch_refresh(c->image_buffer, c->ray_buffer, c->diff_buffer, c->diff_pixels, c->cfg.adaptive_sampling, n, c->stream);
     HIP_TRY(hipGetLastError());
     return RTPBR_OK;
 }
@@ -375,6 +387,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.image_buffer = c->image_buffer;
     P.image_pixels = c->image_pixels;
     P.ray_buffer = c->ray_buffer;
+    P.diff_buffer = c->diff_buffer;
+    P.diff_pixels = c->diff_pixels;
     P.objfull = c->objfull;
     P.work_counter = c->work_counter;
     P.counters = c->counters;
@@ -468,6 +482,8 @@ extern "C" int rtpbr_post_process(rtpbr_ctx* c) {
     c->P.cfg = c->cfg;
     c->P.image_buffer = c->image_buffer;
     c->P.image_pixels = c->image_pixels;
+    c->P.diff_buffer = c->diff_buffer;
+    c->P.diff_pixels = c->diff_pixels;
     launch_post_process(c->P, c->stream);
     HIP_TRY(hipGetLastError());
     return RTPBR_OK;
@@ -487,6 +503,8 @@ static int buf_ptr(rtpbr_ctx* c, int which, void** p, size_t* n) {
         case RTPBR_BUF_IMAGE_BUFFER: *p = c->image_buffer; *n = np * 16; return 0;
         case RTPBR_BUF_IMAGE_PIXELS: *p = c->image_pixels; *n = np * 12; return 0;
         case RTPBR_BUF_RAY_BUFFER: *p = c->ray_buffer; *n = np * sizeof(rtpbr_ray); return 0;
+        case RTPBR_BUF_DIFF_BUFFER: *p = c->diff_buffer; *n = np * 8; return 0;
+        case RTPBR_BUF_DIFF_PIXELS: *p = c->diff_pixels; *n = np * 4; return 0;
     }
     return fail(RTPBR_EINVAL, "unknown buffer id");
 }

@@ -470,7 +470,7 @@ RT_D vec3 aces_fit(vec3 c, int trunc) {
 }
 RT_D float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 RT_D vec3 clamp01(vec3 c) { return mk(clamp01(c.x), clamp01(c.y), clamp01(c.z)); }
-RT_D vec3 pow3(vec3 c, float e) { return mk(powf(c.x, e), powf(c.y, e), powf(c.z, e)); }
+RT_D vec3 pow3(vec3 c, float e) { return mk(pow_(c.x, e), pow_(c.y, e), pow_(c.z, e)); }
 
 RT_D vec3 tone_map(const rtpbr_config& g, float4 b) {
     vec3 c = mk(b.x / b.w, b.y / b.w, b.z / b.w);

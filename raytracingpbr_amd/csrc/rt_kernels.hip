@@ -475,6 +475,8 @@ __global__ void __launch_bounds__(256) persistent_steps(const Params P, int step
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     int px = 0, py = 0;
     bool valid = q < (uint32_t)P.np && pixel_of(P, q, px, py);
+    // self-adaptive sampling mask (src/pathtracer.py:97-101)
+    if (valid && P.cfg.adaptive_sampling && !(P.diff_pixels[(size_t)px * P.cfg.height + py] > P.cfg.noise_threshold)) valid = false;
     uint32_t n_steps = 0, n_raycasts = 0, n_hits = 0, n_sky = 0, n_samples = 0, n_dep = 0;
     if (valid) {
         const rtpbr_config& g = P.cfg;
@@ -560,11 +562,16 @@ __global__ void __launch_bounds__(256) persistent_steps(const Params P, int step
 
 // -------------------------------------------------------------------------------------------
 // refresh() src/renderer.py:12-22
-__global__ void refresh_kernel(float4* image_buffer, rtpbr_ray* ray_buffer, size_t n) {
+__global__ void refresh_kernel(float4* image_buffer, rtpbr_ray* ray_buffer, float2* diff_buffer, float* diff_pixels,
+                               int adaptive, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     image_buffer[i] = make_float4(0, 0, 0, 0);
     ray_buffer[i].depth = 0;
+    if (adaptive) {  // src/renderer.py:19-21
+        diff_buffer[i] = make_float2(1.0f, 1.0f);
+        diff_pixels[i] = 1e32f;
+    }
 }
 
 // post_process() src/postprocessor.py:24-43
@@ -572,10 +579,19 @@ __global__ void post_process_kernel(const Params P) {
     size_t n = (size_t)P.cfg.width * P.cfg.height;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    vec3 last = mk(P.image_pixels[i * 3 + 0], P.image_pixels[i * 3 + 1], P.image_pixels[i * 3 + 2]);
     vec3 c = tone_map(P.cfg, P.image_buffer[i]);
     P.image_pixels[i * 3 + 0] = c.x;
     P.image_pixels[i * 3 + 1] = c.y;
     P.image_pixels[i * 3 + 2] = c.z;
+    if (P.cfg.adaptive_sampling) {  // src/postprocessor.py:40-43
+        vec3 dc = mk(fabs_(c.x - last.x), fabs_(c.y - last.y), fabs_(c.z - last.z));
+        float2 d = P.diff_buffer[i];
+        d.x += brightness(dc);
+        d.y += 1.0f;
+        P.diff_buffer[i] = d;
+        P.diff_pixels[i] = d.x / d.y;
+    }
 }
 
 // tile pack / unpack for the multi-GPU gather
@@ -608,6 +624,8 @@ __global__ void math_probe(int op, const float* a, const float* b, float* out, f
         case 4: r = sqrt_(x); break;
         case 5: r = x / y; break;
         case 7: r = sin_pi_(x); break;
+        case 8: r = log_(x); break;
+        case 9: r = pow_(x, y); break;
         case 6: { uint32_t n0 = __builtin_bit_cast(uint32_t, y); r = rng_next(__builtin_bit_cast(uint32_t, x), n0); } break;
         default: break;
     }
@@ -662,9 +680,9 @@ void launch_persistent(const Params& P, int kind, int steps, hipStream_t st) {
     else if (kind == KIND_MIXED) hipLaunchKernelGGL((persistent_steps<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P, steps);
     else hipLaunchKernelGGL((persistent_steps<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
 }
-void launch_refresh(float4* ib, rtpbr_ray* rb, size_t n, hipStream_t st) {
+void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st) {
     int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(refresh_kernel, dim3(grid), dim3(256), 0, st, ib, rb, n);
+    hipLaunchKernelGGL(refresh_kernel, dim3(grid), dim3(256), 0, st, ib, rb, db, dp, adaptive, n);
 }
 void launch_post_process(const Params& P, hipStream_t st) {
     size_t n = (size_t)P.cfg.width * P.cfg.height;

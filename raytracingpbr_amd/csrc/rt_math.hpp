@@ -143,6 +143,47 @@ RT_HD float exp_(float x) {
     return e * __builtin_bit_cast(float, bits);
 }
 
+// log (Cephes logf) and pow(x, y) = exp(y*log(x)) for x >= 0 (tone map, env preprocess);
+// x < 0 gives NaN like powf.
+RT_HD float log_(float x) {
+    int e = 0;
+    if (x < 1.17549435e-38f) {
+        x = x * 16777216.0f;
+        e = -24;
+    }
+    uint32_t b = __builtin_bit_cast(uint32_t, x);
+    e += (int)((b >> 23) & 0xffu) - 126;
+    b = (b & 0x807fffffu) | 0x3f000000u;
+    float m = __builtin_bit_cast(float, b);
+    if (m < 0.707106781186547524f) {
+        e -= 1;
+        m = m + m - 1.0f;
+    } else {
+        m = m - 1.0f;
+    }
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = fma_(y, m, -1.1514610310e-1f);
+    y = fma_(y, m, 1.1676998740e-1f);
+    y = fma_(y, m, -1.2420140846e-1f);
+    y = fma_(y, m, 1.4249322787e-1f);
+    y = fma_(y, m, -1.6668057665e-1f);
+    y = fma_(y, m, 2.0000714765e-1f);
+    y = fma_(y, m, -2.4999993993e-1f);
+    y = fma_(y, m, 3.3333331174e-1f);
+    y = y * m * z;
+    float fe = (float)e;
+    y = fma_(-2.12194440e-4f, fe, y);
+    y = fma_(-0.5f, z, y);
+    z = m + y;
+    return fma_(0.693359375f, fe, z);
+}
+RT_HD float pow_(float x, float y) {
+    if (x == 0.0f) return 0.0f;
+    if (!(x > 0.0f)) return __builtin_nanf("");
+    return exp_(y * log_(x));
+}
+
 RT_HD float atan_pos_(float x) {
     float y0, z;
     if (x > 2.414213562373095f) {

@@ -18,7 +18,7 @@
 namespace rt {
 
 constexpr int MAX_OBJ = RTPBR_MAX_OBJECTS;
-static_assert(sizeof(rtpbr_config) == 152 && sizeof(rtpbr_object) == 116 && sizeof(rtpbr_camera) == 52 &&
+static_assert(sizeof(rtpbr_config) == 160 && sizeof(rtpbr_object) == 116 && sizeof(rtpbr_camera) == 52 &&
                   sizeof(rtpbr_ray) == 40,
               "C-ABI struct layout changed");
 
@@ -79,6 +79,8 @@ struct Params {
     float4* image_buffer;   // T7 (W,H) float4
     float* image_pixels;    // T8 (W,H,3)
     rtpbr_ray* ray_buffer;  // T6
+    float2* diff_buffer;    // T11
+    float* diff_pixels;     // T11
     const ObjFull* objfull;
     const float4* env;      // T9 as float4 texels [x][y]
     int32_t env_w, env_h;

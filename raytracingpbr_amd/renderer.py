@@ -17,7 +17,7 @@ from .config import FORM, Config
 from .dataclass import Camera, Counters, Ray, SDFObject
 from .scene import Scene
 
-BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS, BUF_RAY_BUFFER = 0, 1, 2
+BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS, BUF_RAY_BUFFER, BUF_DIFF_BUFFER, BUF_DIFF_PIXELS = 0, 1, 2, 3, 4
 ENV_RGB8, ENV_RGB32F = 0, 1
 
 
@@ -108,7 +108,8 @@ class Renderer:
     def _shape(self, which):
         W, H = self.config.width, self.config.height
         return {BUF_IMAGE_BUFFER: ((W, H, 4), np.float32), BUF_IMAGE_PIXELS: ((W, H, 3), np.float32),
-                BUF_RAY_BUFFER: ((W, H, 10), np.float32)}[which]
+                BUF_RAY_BUFFER: ((W, H, 10), np.float32), BUF_DIFF_BUFFER: ((W, H, 2), np.float32),
+                BUF_DIFF_PIXELS: ((W, H), np.float32)}[which]
 
     def _read(self, which):
         shape, dt = self._shape(which)
@@ -143,6 +144,15 @@ class Renderer:
     @ray_buffer.setter
     def ray_buffer(self, arr):
         self._write(BUF_RAY_BUFFER, arr)
+
+    @property
+    def diff_buffer(self):
+        """adaptive-sampling statistics (src/fileds.py:21): (sum of display change, count)"""
+        return self._read(BUF_DIFF_BUFFER)
+
+    @property
+    def diff_pixels(self):
+        return self._read(BUF_DIFF_PIXELS)
 
     def ray_depth(self):
         return self.ray_buffer[..., 9].view(np.int32)

@@ -29,6 +29,16 @@ class Case:
         return r
 
 
+class AdaptiveCase(Case):
+    def run(self, r):
+        self.setup(r)
+        r.refresh()
+        for _ in range(self.rounds):
+            r.sample(self.n)
+            r.post_process()
+        return r
+
+
 def _env(w=192, h=96):
     return synthetic_env(w, h, seed=0)
 
@@ -49,6 +59,11 @@ def all_cases():
     c.append(Case("src_persistent_4steps_blackbg", src_scene(aspect=64 / 36),
                   Config.src(64, 36, 8, steps_per_launch=4).copy(primary_miss=1), 8,
                   env=_env(), env_exposure=1.4, env_gamma=2.2))
+    # self-adaptive sampling (ADAPTIVE_SAMPLING=True, src/config.py:14): refresh, then rounds of
+    # (pathtrace x n, post_process); pixels whose display value stopped changing drop out
+    c.append(AdaptiveCase("src_adaptive_sampling", src_scene(aspect=64 / 36),
+                          Config.src(64, 36, 11, steps_per_launch=2).copy(adaptive_sampling=1, noise_threshold=0.2), 6,
+                          env=_env(), env_exposure=1.4, env_gamma=2.2, rounds=8))
     c.append(Case("bunny_glass", bunny(aspect=64 / 36), Config.bunny_glass(64, 36, 9, 16, frame=0).copy(max_raymarch=512), 2,
                   env=_env(), env_exposure=1.8, env_gamma=2.2))
     c.append(Case("bunny_chrome_frame30", bunny(aspect=48 / 27, chrome=True),

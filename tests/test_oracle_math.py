@@ -42,6 +42,20 @@ def test_sin_pi_for_mlp_activations(oracle_lib):
     assert f(0.0) == 0.0
 
 
+def test_log_pow(oracle_lib):
+    fl = _f(oracle_lib, "rto_test_log", C.c_float, [C.c_float])
+    fp = _f(oracle_lib, "rto_test_pow", C.c_float, [C.c_float, C.c_float])
+    for x in np.concatenate([np.logspace(-30, 30, 1201), [1.0, 0.5, 2.0, 1e-40]]).astype(np.float32):
+        assert abs(fl(float(x)) - np.log(np.float64(x))) <= 2e-7 * max(1.0, abs(np.log(np.float64(x))))
+    assert fl(1.0) == 0.0
+    for x in np.linspace(1e-4, 20, 2001).astype(np.float32):
+        for y in (1 / 2.2, 2.2):
+            ref = np.float64(x) ** y
+            assert abs(fp(float(x), y) - ref) <= 2e-6 * ref
+    assert fp(0.0, 0.45) == 0.0 and np.isnan(fp(-1.0, 0.45))
+    assert abs(fp(1.4, 2.2) - 2.0964) < 1e-3                 # max env value (1.4)^2.2 = 2.10
+
+
 def test_exp(oracle_lib):
     f = _f(oracle_lib, "rto_test_exp", C.c_float, [C.c_float])
     assert f(0.0) == 1.0
