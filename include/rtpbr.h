@@ -300,8 +300,11 @@ int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking
 int rtpbr_last_sample_ms(rtpbr_ctx* ctx, float* trace_ms, float* total_ms, int* launches);
 /* Raw stream handle (hipStream_t) so callers can order their own work after ours. */
 int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
-/* Tuning knobs that do not change results: key in {"staging_bytes","wait_lanes",
- * "scheduler","waves_per_cu"}.  Returns RTPBR_EINVAL for unknown keys. */
+/* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),
+ * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
+ * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes" (scheduler 1), "waves_per_cu",
+ * "sample_base" (absolute index of the next sample: checkpoint/resume).
+ * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */
 int rtpbr_set_option(rtpbr_ctx* ctx, const char* key, long long value);
 
 #ifdef __cplusplus

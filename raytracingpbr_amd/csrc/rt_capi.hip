@@ -18,6 +18,8 @@ namespace rt {
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
 void launch_accumulate(const Params& P, hipStream_t st);
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
+void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
+int persistent_pool_blocks_per_cu(int kind);
 void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st);
 void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
@@ -76,7 +78,7 @@ struct rtpbr_ctx {
     int wait_lanes = 24;
     int shade_lanes = 56;
     int swap_lanes = 8;
-    int scheduler = 1;
+    int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
     std::vector<hipEvent_t> ev;
@@ -365,7 +367,7 @@ static hipEvent_t next_event(rtpbr_ctx* c) {
 }
 
 static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
-    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->scheduler);
+    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->scheduler < 0 ? 1 : c->scheduler);
     if (per_cu <= 0) per_cu = 2;
     if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
     long long grid = (long long)per_cu * c->n_cu;
@@ -395,7 +397,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.wait_lanes = c->wait_lanes;
     P.shade_lanes = c->shade_lanes;
     P.swap_lanes = c->swap_lanes;
-    P.scheduler = c->scheduler;
+    P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
@@ -415,7 +417,25 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             P.sample_base = c->sample_base;
             hipEvent_t a = next_event(c), b = next_event(c);
             HIP_TRY(hipEventRecord(a, c->stream));
-            launch_persistent(P, c->kind, steps, c->stream);
+            const bool use_pool = c->scheduler == 1 || (c->scheduler < 0 && P.np >= (1 << 20));
+            if (use_pool) {
+                // pool scheduler: work items are pixels, claimed in chunks by persistent waves
+                int per_cu = persistent_pool_blocks_per_cu(c->kind);
+                if (per_cu <= 0) per_cu = 2;
+                long long grid = (long long)per_cu * c->n_cu;
+                long long need = ((long long)P.np + 127) / 128;      // 128 contexts per wave
+                need = (need + 3) / 4;
+                if (grid > need) grid = need;
+                if (grid < 1) grid = 1;
+                P.total_items = (uint32_t)P.np;
+                long long chunk = (long long)P.np / (grid * 4 * 8);
+                if (chunk < 64) chunk = 64;
+                if (chunk > 1024) chunk = 1024;
+                P.chunk = (uint32_t)chunk;
+                HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
+                launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+            } else
+                launch_persistent(P, c->kind, steps, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
             c->sample_base += (uint32_t)steps;
             left -= steps;
@@ -615,7 +635,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 1..64");
         c->swap_lanes = (int)value;
     } else if (!strcmp(key, "scheduler")) {
-        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "scheduler must be 0 or 1");
+        if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "scheduler must be -1 (auto), 0 or 1");
         c->scheduler = (int)value;
     } else if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(RTPBR_EINVAL, "waves_per_cu must be 0..32");

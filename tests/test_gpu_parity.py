@@ -149,6 +149,26 @@ def test_schedule_independence():
     assert np.all(r.image_buffer[..., 3] == 12.0)
 
 
+def test_persistent_form_schedulers_agree():
+    """src/ form: the lock-step kernel (scheduler 0) and the LDS-pool kernel (scheduler 1) give the
+    same image_buffer AND the same ray_buffer state, for any launch split."""
+    case = case_by_name("src_persistent")
+    ref = None
+    for opts, split in (({"scheduler": 0}, (48,)), ({"scheduler": 1}, (48,)), ({"scheduler": 1, "shade_lanes": 9, "swap_lanes": 3}, (5, 43)),
+                        ({"scheduler": 1, "shade_lanes": 64, "swap_lanes": 1, "waves_per_cu": 4}, (24, 24))):
+        r = Renderer(case.scene, case.cfg)
+        case.setup(r)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        for n in split:
+            r.sample(n)
+        got = (bits(r.image_buffer), bits(r.ray_buffer))
+        if ref is None:
+            ref = got
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), opts
+        r.close()
+
+
 def test_tile_partition_pack_unpack_is_bit_exact():
     """G virtual ranks on one device: each renders its tiles, packs them on the device, rank 0
     unpacks -> identical to the untiled frame (SURVEY.md §8(e) testability row)."""
