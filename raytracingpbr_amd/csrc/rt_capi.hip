@@ -78,6 +78,7 @@ struct rtpbr_ctx {
     int wait_lanes = 24;
     int shade_lanes = 56;
     int swap_lanes = 8;
+    int mlp_lanes = 48;
     int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
@@ -256,7 +257,7 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
     }
     c->n_obj = n;
     c->P.n_obj = n;
-    c->kind = all_box ? KIND_BOXES : all_bunny ? KIND_BUNNY : any_bunny ? KIND_MIXED : KIND_GENERIC;
+    c->kind = all_box ? KIND_BOXES : (all_bunny && n == 1) ? KIND_BUNNY : any_bunny ? KIND_MIXED : KIND_GENERIC;
     HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
     c->have_scene = true;
@@ -397,6 +398,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.wait_lanes = c->wait_lanes;
     P.shade_lanes = c->shade_lanes;
     P.swap_lanes = c->swap_lanes;
+    P.mlp_lanes = c->mlp_lanes;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
@@ -631,6 +633,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "mlp_lanes")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "mlp_lanes must be 1..64");
+        c->mlp_lanes = (int)value;
     } else if (!strcmp(key, "swap_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 1..64");
         c->swap_lanes = (int)value;

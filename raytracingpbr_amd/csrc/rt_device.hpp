@@ -27,9 +27,8 @@ typedef const __attribute__((address_space(4))) float* CFloatPtr;
 typedef const float* CFloatPtr;
 #endif
 
-RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
-    float len = length(p);
-    if (len > 1.0f || wg == nullptr) return len - 0.8f;
+// the MLP proper; valid inside the unit sphere (the caller has done the bounding-sphere test)
+RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
     CFloatPtr w = (CFloatPtr)wg;
     asm volatile("" : "+s"(w));
     float f0[16], f1[16];
@@ -72,6 +71,13 @@ RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
 #pragma unroll
     for (int t = 1; t < 16; t++) sd = fma_(f0[t], ow[t], sd);
     return sd + ow[16];
+}
+
+// bunny_sdf_glass.py:150-153: outside the unit sphere the SDF is the distance to a 0.8 sphere
+RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
+    float len = length(p);
+    if (len > 1.0f || wg == nullptr) return len - 0.8f;
+    return bunny_mlp(wg, p);
 }
 
 // ---------------------------------------------------------------- F10 SDF primitives
@@ -224,13 +230,8 @@ RT_D void march_init(const Params& P, Lane& L) {
 
 // One iteration of the examples' raycast loop.  plain: cornell_box_v2.py:186-196;
 // relaxed: cornell_box_v3/pathtracer.py:57-76, tokyo_ibl.py:249-263, bunny_sdf_glass.py:252-265.
-template <int KIND, int NOBJ>
-RT_D void march_step(const Params& P, Lane& L) {
-    vec3 pos = fma3(L.t, L.d, L.o);
-    L.t_eval = L.t;
-    int idx;
-    float dist;
-    nearest<KIND, NOBJ>(P, pos, idx, dist);
+// The part of one raycast iteration after nearest(): relaxation / hit / escape bookkeeping.
+RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
     L.idx = idx;
     L.n_steps++;
     L.steps_left--;
@@ -249,7 +250,7 @@ RT_D void march_step(const Params& P, Lane& L) {
         // normal branch: err = d / t; hit = err < PIXEL_RADIUS.  The correctly rounded quotient
         // is only needed when d is within 2^-20 (relative) of t*eps; otherwise the comparison is
         // decided by the product (monotone rounding), which saves the 11-instruction divide on
-        // practically every step.  Wave-uniform branch: taken if ANY lane is in the band.
+        // practically every step.  Wave-uniform branch: taken if ANY active lane is in the band.
         float te = L.t * P.cfg.hit_eps;
         bool sure_hit = dist < te * 0.99999905f;
         bool sure_miss = dist > te * 1.00000095f;
@@ -269,6 +270,40 @@ RT_D void march_step(const Params& P, Lane& L) {
     }
     done = done || (L.steps_left == 0);
     if (done) L.state = hit ? ST_HIT : ST_MISS;
+}
+
+template <int KIND, int NOBJ>
+RT_D void march_step(const Params& P, Lane& L) {
+    vec3 pos = fma3(L.t, L.d, L.o);
+    L.t_eval = L.t;
+    int idx;
+    float dist;
+    nearest<KIND, NOBJ>(P, pos, idx, dist);
+    march_update(P, L, idx, dist);
+}
+
+// Single-bunny scenes: the cheap half of nearest().  Returns true when the position is inside the
+// unit sphere, i.e. the MLP is needed (local position in lp); otherwise dist is final.
+RT_D bool bunny_pre(const Params& P, Lane& L, vec3& lp, float& dist) {
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    const ObjM o = tab[0];
+    vec3 pos = fma3(L.t, L.d, L.o);
+    L.t_eval = L.t;
+    vec3 l = to_local<KIND_BUNNY>(P, o, pos);
+    float len = length(l);
+    if (len > 1.0f || P.bunny == nullptr) {
+        dist = fabs_(len - 0.8f);
+        if (P.cfg.nearest_init) dist = fmin_(dist, P.cfg.max_dis);
+        return false;
+    }
+    lp = l;
+    return true;
+}
+RT_D float bunny_post(const Params& P, vec3 lp) {
+    float dist = fabs_(bunny_mlp(P.bunny, lp));
+    if (P.cfg.nearest_init) dist = fmin_(dist, P.cfg.max_dis);
+    return dist;
 }
 
 // ---------------------------------------------------------------- F11 normal

@@ -293,6 +293,8 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
     uint32_t n_samples = 0;
     WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
+    bool b_pending = false;                         // bunny: position evaluated, MLP still to run
+    vec3 b_lp = mk(0, 0, 0);
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
 
@@ -434,7 +436,30 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
             const int n_ready = __popcll(m_ready);
             int n_done;
             do {
-                if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+                if (KIND == KIND_BUNNY && P.n_obj == 1) {
+                    // The neural SDF costs ~1700 instructions, the bounding-sphere branch ~40.  Lanes outside
+                    // the unit sphere RUN AHEAD with cheap steps until they enter it (pending) or finish, so
+                    // the MLP is evaluated once for as many lanes as possible instead of once per step for
+                    // whichever few lanes happen to be inside.
+                    for (;;) {
+                        const bool can = L.state == ST_MARCH && !b_pending;
+                        if (!__any(can)) break;
+                        if (can) {
+                            float dist;
+                            if (bunny_pre(P, L, b_lp, dist)) b_pending = true;
+                            else march_update(P, L, 0, dist);
+                        }
+                        if (__popcll(__ballot(b_pending)) >= P.mlp_lanes) break;
+                    }
+                    if (__any(b_pending)) {
+                        if (b_pending) {
+                            march_update(P, L, 0, bunny_post(P, b_lp));
+                            b_pending = false;
+                        }
+                    }
+                } else {
+                    if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+                }
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
                 n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
                 // keep marching until enough lanes want a swap; with no READY ray parked, finished lanes

@@ -1,0 +1,20 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracingpbr_amd import SHAPE, Config, Renderer, bunny
+from raytracingpbr_amd.ibl import load_bunny_weights, synthetic_env
+from oracle_backend import OracleRenderer
+env = synthetic_env(3072, 1536, seed=0)
+def mk(R, sc, cfg):
+    r = R(sc, cfg); r.set_env(env, 1.8, 2.2); r.set_shape_data(SHAPE.BUNNY, load_bunny_weights()); return r
+sc = bunny(aspect=16 / 9); cfg = Config.bunny_glass(160, 90, 0, 16)
+g = mk(Renderer, sc, cfg); g.sample(4); o = mk(OracleRenderer, sc, cfg); o.sample(4)
+print("bit-exact:", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)))
+cfg = Config.bunny_glass(1920, 1080, 0, 16)
+for opts in ({"scheduler": 0}, {"mlp_lanes": 1}, {"mlp_lanes": 32}, {"mlp_lanes": 48}, {"mlp_lanes": 64}, {"mlp_lanes": 64, "swap_lanes": 16}, {"mlp_lanes": 64, "swap_lanes": 4}):
+    r = mk(Renderer, sc, cfg)
+    for k, v in opts.items(): r.set_option(k, v)
+    r.sample(2); r.sync(); r.sample(16); tr, tot, n = r.last_sample_ms(); c = r.counters()
+    print(opts, f"ms={tr:.2f} Msamples/s={c.samples / tr / 1e3:.1f}", flush=True)
+    r.close()
