@@ -27,7 +27,58 @@ typedef const __attribute__((address_space(4))) float* CFloatPtr;
 typedef const float* CFloatPtr;
 #endif
 
-// the MLP proper; valid inside the unit sphere (the caller has done the bounding-sphere test)
+// the MLP proper; valid inside the unit sphere (the caller has done the bounding-sphere test).
+// Weights stream through SGPRs in 16-dword blocks (one s_load_dwordx16 = one mat4 = 16 fmas);
+// the loads are software-pipelined two blocks ahead of their use (sched_barrier pins the issue
+// point) so the scalar-cache latency hides behind the arithmetic of the previous blocks.
+typedef float f16v __attribute__((ext_vector_type(16)));
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) f16v* CF16Ptr;
+#define RT_LD16(ptr, off) (*(CF16Ptr)((ptr) + (off)))
+#define RT_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RT_LD16(ptr, off) (*(const f16v*)((ptr) + (off)))
+#define RT_PIN()
+#endif
+
+// one 16 -> 16 layer: out[k*4+j] = act(sum_t in[t]*W_k[(t>>2)*16+(t&3)*4+j] + b_k[j]) (/1.4) + in[k*4+j]
+template <bool DIV>
+RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
+    // block b = k*4 + m lives at lw + k*68 + m*16
+    f16v w0 = RT_LD16(lw, 0);
+    f16v w1 = RT_LD16(lw, 16);
+    RT_PIN();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int b = k * 4 + m;
+            // request block b+2 before block b is consumed
+            const int nb = b + 2 < 16 ? b + 2 : 15;
+            f16v w2 = RT_LD16(lw, (nb >> 2) * 68 + (nb & 3) * 16);
+            RT_PIN();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const float x = in[m * 4 + i];
+                    acc[jj] = (m == 0 && i == 0) ? x * w0[i * 4 + jj] : fma_(x, w0[i * 4 + jj], acc[jj]);
+                }
+            }
+            w0 = w1;
+            w1 = w2;
+        }
+        CFloatPtr bias = lw + k * 68 + 64;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+            float sn = sin_pi_(acc[jj] + bias[jj]);
+            if (DIV) sn = sn / 1.4f;
+            out[k * 4 + jj] = sn + in[k * 4 + jj];
+        }
+    }
+}
+
 RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
     CFloatPtr w = (CFloatPtr)wg;
     asm volatile("" : "+s"(w));
@@ -42,30 +93,8 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
             f0[k * 4 + j] = sin_pi_(a + b[12 + j]);
         }
     }
-    // layer 1: f1 = sin(f0 @ W1 + b1) + f0
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        CFloatPtr bw = w + 64 + k * 68;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float acc = f0[0] * bw[j];
-#pragma unroll
-            for (int t = 1; t < 16; t++) acc = fma_(f0[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
-            f1[k * 4 + j] = sin_pi_(acc + bw[64 + j]) + f0[k * 4 + j];
-        }
-    }
-    // layer 2 (f2 overwrites f0): f2 = sin(f1 @ W2 + b2) / 1.4 + f1
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        CFloatPtr bw = w + 64 + 272 + k * 68;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float acc = f1[0] * bw[j];
-#pragma unroll
-            for (int t = 1; t < 16; t++) acc = fma_(f1[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
-            f0[k * 4 + j] = sin_pi_(acc + bw[64 + j]) / 1.4f + f1[k * 4 + j];
-        }
-    }
+    bunny_layer<false>(w + 64, f0, f1);         // f1 = sin(f0 @ W1 + b1) + f0
+    bunny_layer<true>(w + 64 + 272, f1, f0);    // f2 = sin(f1 @ W2 + b2) / 1.4 + f1   (f2 overwrites f0)
     CFloatPtr ow = w + 64 + 544;
     float sd = f0[0] * ow[0];
 #pragma unroll

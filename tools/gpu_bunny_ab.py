@@ -12,9 +12,15 @@ sc = bunny(aspect=16 / 9); cfg = Config.bunny_glass(160, 90, 0, 16)
 g = mk(Renderer, sc, cfg); g.sample(4); o = mk(OracleRenderer, sc, cfg); o.sample(4)
 print("bit-exact:", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)))
 cfg = Config.bunny_glass(1920, 1080, 0, 16)
-for opts in ({"scheduler": 0}, {"mlp_lanes": 1}, {"mlp_lanes": 32}, {"mlp_lanes": 48}, {"mlp_lanes": 64}, {"mlp_lanes": 64, "swap_lanes": 16}, {"mlp_lanes": 64, "swap_lanes": 4}):
+variants = [{"scheduler": 0}, {"mlp_lanes": 1}, {"mlp_lanes": 32}, {"mlp_lanes": 48}, {"mlp_lanes": 64}]
+rs = []
+for opts in variants:
     r = mk(Renderer, sc, cfg)
     for k, v in opts.items(): r.set_option(k, v)
-    r.sample(2); r.sync(); r.sample(16); tr, tot, n = r.last_sample_ms(); c = r.counters()
-    print(opts, f"ms={tr:.2f} Msamples/s={c.samples / tr / 1e3:.1f}", flush=True)
-    r.close()
+    r.sample(2); r.sync(); rs.append(r)
+best = [1e9] * len(variants)
+for rep in range(4):                      # interleaved repetitions: same box, same thermal state
+    for i, r in enumerate(rs):
+        r.sample(16); tr, tot, n = r.last_sample_ms(); best[i] = min(best[i], tr)
+for opts, b in zip(variants, best):
+    print(opts, f"best ms={b:.2f} Msamples/s={1920 * 1080 * 16 / b / 1e3:.1f}", flush=True)
