@@ -74,7 +74,7 @@ struct rtpbr_ctx {
     uint32_t sample_base = 0;
     unsigned long long deposits_host = 0;
     // options
-    long long staging_bytes = 2LL << 30;
+    long long staging_bytes = 10LL << 30;  // 288 GB of HBM: stage a whole 1080p x 256 spp step (8.5 GB) in one launch
     int wait_lanes = 24;
     int shade_lanes = 56;
     int swap_lanes = 8;
