@@ -521,7 +521,7 @@ static float sd_bunny(v3 p) {
     for (int k = 0; k < 4; k++) {
         const float* b = w + k * 16;
         for (int j = 0; j < 4; j++) {
-            float a = fmaf(p.z, b[4 + j], p.y * b[j]);
+            float a = fmaf(p.z, b[4 + j], fmaf(p.y, b[j], 0.0f));
             a = fmaf(-p.x, b[8 + j], a);
             f0[k * 4 + j] = rto_sin_pi(a + b[12 + j]);
         }
@@ -534,8 +534,8 @@ static float sd_bunny(v3 p) {
         for (int k = 0; k < 4; k++) {
             const float* bw = lw + k * 68;
             for (int j = 0; j < 4; j++) {
-                float acc = src[0] * bw[j];
-                for (int t = 1; t < 16; t++) acc = fmaf(src[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
+                float acc = 0.0f;   /* k-ordered fma chain from +0: what an f32 MFMA computes */
+                for (int t = 0; t < 16; t++) acc = fmaf(src[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
                 float sn = rto_sin_pi(acc + bw[64 + j]);
                 if (layer == 1) sn = sn / 1.4f;
                 dst[k * 4 + j] = sn + src[k * 4 + j];

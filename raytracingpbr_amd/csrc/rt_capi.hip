@@ -79,6 +79,7 @@ struct rtpbr_ctx {
     int shade_lanes = 56;
     int swap_lanes = 8;
     int mlp_lanes = 48;
+    int mlp_mfma = 1;
     int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
@@ -399,7 +400,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.shade_lanes = c->shade_lanes;
     P.swap_lanes = c->swap_lanes;
     P.mlp_lanes = c->mlp_lanes;
+    P.mlp_mfma = c->mlp_mfma;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
+    if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
@@ -633,6 +636,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "mlp_mfma")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "mlp_mfma must be 0 or 1");
+        c->mlp_mfma = (int)value;
     } else if (!strcmp(key, "mlp_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "mlp_lanes must be 1..64");
         c->mlp_lanes = (int)value;

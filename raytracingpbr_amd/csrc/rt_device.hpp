@@ -63,7 +63,7 @@ RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
                     const float x = in[m * 4 + i];
-                    acc[jj] = (m == 0 && i == 0) ? x * w0[i * 4 + jj] : fma_(x, w0[i * 4 + jj], acc[jj]);
+                    acc[jj] = fma_(x, w0[i * 4 + jj], (m == 0 && i == 0) ? 0.0f : acc[jj]);
                 }
             }
             w0 = w1;
@@ -88,7 +88,7 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
         CFloatPtr b = w + k * 16;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float a = fma_(p.z, b[4 + j], p.y * b[j]);
+            float a = fma_(p.z, b[4 + j], fma_(p.y, b[j], 0.0f));
             a = fma_(-p.x, b[8 + j], a);
             f0[k * 4 + j] = sin_pi_(a + b[12 + j]);
         }
@@ -99,6 +99,103 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
     float sd = f0[0] * ow[0];
 #pragma unroll
     for (int t = 1; t < 16; t++) sd = fma_(f0[t], ow[t], sd);
+    return sd + ow[16];
+}
+
+// ---- wave-cooperative MLP on the matrix cores -------------------------------------------------
+// The two 16x16 layers (and the 4x16 input layer) are dense contractions over the 64 rays of a
+// wave, so they run as v_mfma_f32_16x16x4_f32: f32 in / f32 accumulate, bit-for-bit a k-ordered
+// fmaf chain from C (MI355X guide §3) — the same chain the VALU version and the oracle compute, so
+// results stay bit-identical.  Weights live in 9 VGPRs per lane as B fragments (loaded once per
+// kernel): no scalar-load stalls and half of the eval's arithmetic moves off the VALU.
+// Layouts (16x16x4): A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
+// C/D: lane l, reg v holds D[i=(l>>4)*4+v][j=l&15].  i = ray within a block of 16, j = neuron.
+// Activations stay in D layout; between layers they pass through a wave-private LDS buffer
+// [t][ray] (row stride 80 words: conflict-free for both access patterns) to become A fragments.
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int BUNNY_LDS_STRIDE = 80;
+constexpr int BUNNY_LDS_WORDS = 16 * BUNNY_LDS_STRIDE;
+
+struct BunnyFrag {
+    float b0;        // input layer  B[k][j], rows k = (wy, wz, wx, bias)
+    float b1[4];     // layer 1      B_kb[k][j] = W1[t = 4kb+k][j]
+    float b2[4];     // layer 2
+    float bias1, bias2;
+};
+
+RT_D void bunny_frag_load(const float* __restrict__ w, int lane, BunnyFrag& F) {
+    const int k = lane >> 4, j = lane & 15, blk = j >> 2, jj = j & 3;
+    F.b0 = w[blk * 16 + k * 4 + jj];
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        F.b1[kb] = w[64 + blk * 68 + kb * 16 + k * 4 + jj];
+        F.b2[kb] = w[64 + 272 + blk * 68 + kb * 16 + k * 4 + jj];
+    }
+    F.bias1 = w[64 + blk * 68 + 64 + jj];
+    F.bias2 = w[64 + 272 + blk * 68 + 64 + jj];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+RT_D f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#else
+RT_D f4v mfma4(float, float, f4v c) { return c; }
+#endif
+
+// MUST be called by all 64 lanes (wave-uniform control flow).  lp = this lane's local point
+// (garbage allowed for lanes that do not need a result: rows are independent).  Returns the MLP
+// value for this lane's point.
+RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, float* lds, int lane, vec3 lp) {
+    const int li = lane & 15, lk = lane >> 4;
+    f4v act[4], acc[4];
+    // ---- input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b), one MFMA per block of 16 rays
+    lds[0 * BUNNY_LDS_STRIDE + lane] = lp.y;
+    lds[1 * BUNNY_LDS_STRIDE + lane] = lp.z;
+    lds[2 * BUNNY_LDS_STRIDE + lane] = -lp.x;
+    lds[3 * BUNNY_LDS_STRIDE + lane] = 1.0f;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+        float a = lds[lk * BUNNY_LDS_STRIDE + rb * 16 + li];
+        f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4v d = mfma4(a, F.b0, z);
+#pragma unroll
+        for (int v = 0; v < 4; v++) act[rb][v] = sin_pi_(d[v]);
+        RT_PIN();   // 4 activations at a time: interleaving all 16 sine evaluations costs ~80 VGPRs
+    }
+    // ---- two hidden layers
+#pragma unroll
+    for (int layer = 0; layer < 2; layer++) {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)   // D layout -> LDS [t = neuron][ray]
+            *reinterpret_cast<f4v*>(&lds[li * BUNNY_LDS_STRIDE + rb * 16 + lk * 4]) = act[rb];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                float a = lds[(kb * 4 + lk) * BUNNY_LDS_STRIDE + rb * 16 + li];
+                c = mfma4(a, layer == 0 ? F.b1[kb] : F.b2[kb], c);
+            }
+            acc[rb] = c;
+        }
+        const float bias = layer == 0 ? F.bias1 : F.bias2;
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                float sn = sin_pi_(acc[rb][v] + bias);
+                if (layer == 1) sn = sn / 1.4f;
+                act[rb][v] = sn + act[rb][v];
+            }
+            RT_PIN();
+        }
+    }
+    // ---- output: back to lane = ray, 16-term chain with the (uniform) output weights
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) *reinterpret_cast<f4v*>(&lds[li * BUNNY_LDS_STRIDE + rb * 16 + lk * 4]) = act[rb];
+    CFloatPtr ow = (CFloatPtr)wg + 64 + 544;
+    float sd = lds[lane] * ow[0];
+#pragma unroll
+    for (int t = 1; t < 16; t++) sd = fma_(lds[t * BUNNY_LDS_STRIDE + lane], ow[t], sd);
     return sd + ow[16];
 }
 
@@ -334,6 +431,11 @@ RT_D float bunny_post(const Params& P, vec3 lp) {
     if (P.cfg.nearest_init) dist = fmin_(dist, P.cfg.max_dis);
     return dist;
 }
+RT_D float bunny_post_value(const Params& P, float sd) {
+    float dist = fabs_(sd);
+    if (P.cfg.nearest_init) dist = fmin_(dist, P.cfg.max_dis);
+    return dist;
+}
 
 // ---------------------------------------------------------------- F11 normal
 // world: cornell_box_v3/sdf.py:26-31; local: src/sdf.py:77-87 + src/scene.py:87-96
@@ -382,6 +484,35 @@ RT_D vec3 calc_normal(const Params& P, const ObjFull& o, vec3 p) {
     }
 }
 
+// calc_normal for the single-bunny kind with the MLP on the matrix cores: same arithmetic as the
+// rolled loop in calc_normal (tetrahedron offsets, signed distance of the one object), but the
+// four MLP evaluations are wave-cooperative, so ALL 64 lanes must call this (uniform flow);
+// lanes without a hit pass any position and ignore the result.
+RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, int lane, vec3 p) {
+    // the single object's transform comes from the kernarg table (scalar operands, no VGPRs)
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    const ObjM o = tab[0];
+    const float h = P.cfg.normal_h;
+    const bool world = P.cfg.normal_space == RTPBR_NORMAL_WORLD;
+    vec3 q = world ? p : to_local<KIND_BUNNY>(P, o, p);
+    vec3 n = mk(0, 0, 0);
+#pragma nounroll
+    for (int i = 0; i < 4; i++) {
+        float ex = (i == 0 || i == 3) ? 1.0f : -1.0f;
+        float ey = (i >= 2) ? 1.0f : -1.0f;
+        float ez = (i & 1) ? 1.0f : -1.0f;
+        vec3 e = world ? mk(ex * h, ey * h, ez * h) : mk(ex, ey, ez);
+        vec3 l = world ? to_local<KIND_BUNNY>(P, o, q + e) : q + e * h;
+        float len = length(l);
+        float sd = bunny_mlp_wave(F, P.bunny, lds, lane, l);
+        float d = (len > 1.0f) ? len - 0.8f : sd;
+        vec3 t = e * d;
+        n = (i == 0 && world) ? t : n + t;
+    }
+    return normalize(n);
+}
+
 RT_D float brightness(vec3 c) { return dot(c, mk(0.299f, 0.587f, 0.114f)); }  // src/util.py:31-33
 
 // F15: src/util.py:21-28 random_in_unit_sphere + src/pbr.py:16-19 hemispheric_sampling
@@ -399,12 +530,12 @@ RT_D vec3 hemispheric_sampling(vec3 n, uint32_t key, uint32_t& cnt) {
 // ---------------------------------------------------------------- F12/F22 surface interaction
 // src/pbr.py:22-62; cornell_box_v3/pbr.py:30-66; cornell_box_shortest.py:91-94.
 // `origin` is the ray origin (src form: already marched), `pos` the hit position.
-template <int KIND>
+template <int KIND, bool HAVE_NORMAL = false>
 RT_D void surface_interaction(const Params& P, const ObjFull& o, vec3 pos, vec3& origin, vec3& dir, vec3& col,
-                              uint32_t key, uint32_t& cnt) {
+                              uint32_t key, uint32_t& cnt, vec3 given_normal = vec3{0, 0, 0}) {
     const rtpbr_config& g = P.cfg;
     vec3 albedo = mk(o.albedo[0], o.albedo[1], o.albedo[2]);
-    vec3 n = calc_normal<KIND>(P, o, pos);
+    vec3 n = HAVE_NORMAL ? given_normal : calc_normal<KIND>(P, o, pos);
     if (g.surface_kind == RTPBR_SURFACE_DIFFUSE) {
         dir = hemispheric_sampling(n, key, cnt);
         col = col * albedo;

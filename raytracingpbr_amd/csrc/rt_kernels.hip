@@ -71,11 +71,11 @@ struct PathRay {
 
 // after a hit: surface interaction, emission / stop test, next-bounce roulette (:84-89,:97-104).
 // returns true if the path continues with another raycast.
-template <int KIND>
-RT_D bool shade_hit(const Params& P, const ObjFull* lds_obj, PathRay& R) {
+template <int KIND, bool HAVE_NORMAL = false>
+RT_D bool shade_hit(const Params& P, const ObjFull* lds_obj, PathRay& R, vec3 given_normal = vec3{0, 0, 0}) {
     const ObjFull o = lds_obj[R.idx];
     vec3 pos = fma3(R.t_eval, R.d, R.o);
-    surface_interaction<KIND>(P, o, pos, R.o, R.d, R.col, R.key, R.cnt);
+    surface_interaction<KIND, HAVE_NORMAL>(P, o, pos, R.o, R.d, R.col, R.key, R.cnt, given_normal);
     float intensity = brightness(R.col);
     R.col = R.col * mk(o.emission[0], o.emission[1], o.emission[2]);
     float visible = brightness(R.col);
@@ -295,6 +295,10 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
     bool b_pending = false;                         // bunny: position evaluated, MLP still to run
     vec3 b_lp = mk(0, 0, 0);
+    __shared__ float b_lds_all[(KIND == KIND_BUNNY) ? 4 * BUNNY_LDS_WORDS : 4];
+    float* b_lds = &b_lds_all[(KIND == KIND_BUNNY) ? wave * BUNNY_LDS_WORDS : 0];
+    BunnyFrag b_frag = {};
+    if (KIND == KIND_BUNNY && P.bunny != nullptr) bunny_frag_load(P.bunny, lane, b_frag);
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
 
@@ -326,12 +330,29 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
                     R.key = pool[F_KEY][lane];
                     R.cnt = pool[F_CNT][lane];
                     R.item = pool[F_ITEM][lane];
+                    if (KIND != KIND_BUNNY) {
+                        if (st == SL_HIT) {
+                            alive = shade_hit<KIND>(P, lds_obj, R);
+                            L.n_hits++;
+                        } else {
+                            shade_miss(P, R, L.n_sky);
+                        }
+                    }
+                }
+                if (KIND == KIND_BUNNY) {
+                    // the normal's four MLP evaluations run on the matrix cores for the whole wave
+                    // (uniform control flow); only the lanes whose slot holds a hit use the result
+                    vec3 hp = fma3(R.t_eval, R.d, R.o);
+                    vec3 nrm = mk(0, 0, 0);
+                    if (__any(st == SL_HIT)) nrm = bunny_normal_wave(P, b_frag, b_lds, lane, hp);
                     if (st == SL_HIT) {
-                        alive = shade_hit<KIND>(P, lds_obj, R);
+                        alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
                         L.n_hits++;
-                    } else {
+                    } else if (st == SL_MISS) {
                         shade_miss(P, R, L.n_sky);
                     }
+                }
+                if (st == SL_HIT || st == SL_MISS) {
                     if (!alive) {
                         write_sample(P, R.item, R.col, 1.0f);
                         n_samples++;
@@ -436,7 +457,7 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
             const int n_ready = __popcll(m_ready);
             int n_done;
             do {
-                if (KIND == KIND_BUNNY && P.n_obj == 1) {
+                if (KIND == KIND_BUNNY) {
                     // The neural SDF costs ~1700 instructions, the bounding-sphere branch ~40.  Lanes outside
                     // the unit sphere RUN AHEAD with cheap steps until they enter it (pending) or finish, so
                     // the MLP is evaluated once for as many lanes as possible instead of once per step for
@@ -452,8 +473,10 @@ __global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
                         if (__popcll(__ballot(b_pending)) >= P.mlp_lanes) break;
                     }
                     if (__any(b_pending)) {
+                        // all 64 lanes evaluate together on the matrix cores (uniform control flow)
+                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, lane, b_lp);
                         if (b_pending) {
-                            march_update(P, L, 0, bunny_post(P, b_lp));
+                            march_update(P, L, 0, bunny_post_value(P, sd));
                             b_pending = false;
                         }
                     }

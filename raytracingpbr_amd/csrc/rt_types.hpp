@@ -74,6 +74,7 @@ struct Params {
     int32_t shade_lanes;    // pool scheduler: shade when this many parked rays wait
     int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
+    int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)
     // pointers
     float4* stage;

@@ -9,10 +9,13 @@ env = synthetic_env(3072, 1536, seed=0)
 def mk(R, sc, cfg):
     r = R(sc, cfg); r.set_env(env, 1.8, 2.2); r.set_shape_data(SHAPE.BUNNY, load_bunny_weights()); return r
 sc = bunny(aspect=16 / 9); cfg = Config.bunny_glass(160, 90, 0, 16)
-g = mk(Renderer, sc, cfg); g.sample(4); o = mk(OracleRenderer, sc, cfg); o.sample(4)
-print("bit-exact:", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)))
+o = mk(OracleRenderer, sc, cfg); o.sample(4)
+for mf in (0, 1):
+    g = mk(Renderer, sc, cfg); g.set_option("mlp_mfma", mf); g.sample(4)
+    a, b = g.image_buffer, o.image_buffer
+    print("mlp_mfma", mf, "bit-exact:", np.array_equal(a.view(np.uint32), b.view(np.uint32)), "differing pixels", int((a != b).any(axis=2).sum()), g.counters().march_steps, o.counters().march_steps)
 cfg = Config.bunny_glass(1920, 1080, 0, 16)
-variants = [{"scheduler": 0}, {"mlp_lanes": 1}, {"mlp_lanes": 32}, {"mlp_lanes": 48}, {"mlp_lanes": 64}]
+variants = [{"scheduler": 0}, {"mlp_mfma": 0, "mlp_lanes": 48}, {"mlp_mfma": 1, "mlp_lanes": 16}, {"mlp_mfma": 1, "mlp_lanes": 32}, {"mlp_mfma": 1, "mlp_lanes": 48}, {"mlp_mfma": 1, "mlp_lanes": 64}]
 rs = []
 for opts in variants:
     r = mk(Renderer, sc, cfg)
