@@ -159,7 +159,6 @@ RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, floa
         f4v d = mfma4(a, F.b0, z);
 #pragma unroll
         for (int v = 0; v < 4; v++) act[rb][v] = sin_pi_(d[v]);
-        RT_PIN();   // 4 activations at a time: interleaving all 16 sine evaluations costs ~80 VGPRs
     }
     // ---- two hidden layers
 #pragma unroll
@@ -186,7 +185,6 @@ RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, floa
                 if (layer == 1) sn = sn / 1.4f;
                 act[rb][v] = sn + act[rb][v];
             }
-            RT_PIN();
         }
     }
     // ---- output: back to lane = ray, 16-term chain with the (uniform) output weights
