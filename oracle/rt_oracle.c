@@ -653,6 +653,9 @@ int rto_set_threads(struct rto_ctx* c, int n) { c->threads = n; return RTPBR_OK;
 int rto_sample(struct rto_ctx* c, int n) {
     if (!c || !c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "config/scene/camera missing");
     if (n < 0) return fail(RTPBR_EINVAL, "n < 0");
+    if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs set_env first");
+    for (int i = 0; i < c->n_obj; i++)
+        if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !g_bunny_set) return fail(RTPBR_ESTATE, "bunny shape needs set_shape_data first");
     const int W = c->cfg.width, H = c->cfg.height;
     cam_frame f;
     camera_frame(c, &f);

@@ -35,11 +35,12 @@ def run(name, sc, cfg, spp, env=None, envexp=1.8, tiles=None, chunk=None, warm=1
 env3k = synthetic_env(3072, 1536, seed=0)
 run("C1_cornell_256x256_16spp_4b", cornell_box("v3"), Config.cornell_v3(256, 256, 0, 4), 16)
 run("C2_cornell_1080p_256spp_8b", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(1920, 1080, 0, 8), 256)
-spp3 = int(os.environ.get("C3_SPP", "16"))
-run(f"C3_bunny_glass_1080p_{spp3}spp_16b(of 1024)", bunny(aspect=16 / 9), Config.bunny_glass(1920, 1080, 0, 16), spp3, env=env3k, warm=1)
+spp3 = int(os.environ.get("C3_SPP", "1024"))
+run(f"C3_bunny_glass_1080p_{spp3}spp_16b", bunny(aspect=16 / 9), Config.bunny_glass(1920, 1080, 0, 16), spp3, env=env3k, warm=1)
 tw, th = default_tile(3840, 2160, 4)
-run("C4_tokyo_ibl_4k_512spp_rank0of4", src_scene(aspect=16 / 9, tokyo=True), Config.tokyo_ibl(3840, 2160, 0, 512), 512, env=env3k, tiles=(tw, th, 0, 4), chunk=64)
+run("C4_tokyo_ibl_4k_512spp_rank0of4", src_scene(aspect=16 / 9, tokyo=True), Config.tokyo_ibl(3840, 2160, 0, 512), 512, env=env3k, tiles=(tw, th, 0, 4), chunk=256)
 tw, th = default_tile(7680, 4320, 8)
-run("C5_cornell_8k_256spp(of 4096)_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), 256, tiles=(tw, th, 0, 8), chunk=64)
+spp5 = int(os.environ.get("C5_SPP", "4096"))
+run(f"C5_cornell_8k_{spp5}spp_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), spp5, tiles=(tw, th, 0, 8), chunk=256)
 run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4, chunk=64)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
