@@ -332,3 +332,40 @@ def test_fuzz_random_scenes_match_oracle(seed):
     if cfg.kernel_form == 1:
         assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer))
     g.close()
+
+
+def test_edge_cases_match_oracle():
+    """Degenerate sizes: 1x1 frame, 32 objects (RTPBR_MAX_OBJECTS), sample(0), a tile larger than
+    the frame, more ranks than tiles (a rank that owns nothing), odd frame sizes vs tile edges."""
+    from raytracingpbr_amd import SHAPE, Camera, Material, SDFObject, Scene, Transform
+    rng = np.random.default_rng(5)
+    objs = [SDFObject(SHAPE.BOX if i % 2 else SHAPE.SPHERE, Transform(rng.uniform(-3, 3, 3), rng.uniform(-90, 90, 3), rng.uniform(0.2, 0.8, 3)),
+                      Material(rng.uniform(0.2, 1, 3), (1, 1, 1) if i else (30, 30, 30), 1, 0, 0, 1.5)) for i in range(32)]
+    sc = Scene(objs, False, Camera((0, 0, 9), (0, 0, 0), (0, 1, 0), 40, 37 / 23, 0.02, 6))
+    cfg = Config.scene_demo(37, 23, 3, 6)
+    g, o = Renderer(sc, cfg), OracleRenderer(sc, cfg)
+    for r in (g, o):
+        r.sample(0)
+        assert r.counters().samples == 0 and np.all(r.image_buffer == 0)
+        r.sample(3)
+    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+    # 1x1 frame
+    c1 = Config.cornell_v3(1, 1, 0, 4)
+    g1, o1 = Renderer(cornell_box("v3"), c1), OracleRenderer(cornell_box("v3"), c1)
+    g1.sample(33); o1.sample(33)
+    assert np.array_equal(bits(g1.image_buffer), bits(o1.image_buffer)) and g1.image_buffer[0, 0, 3] == 33
+    # tile larger than the frame, and 5 ranks over 2 tiles: ranks 2..4 own nothing
+    full = Renderer(sc, cfg); full.sample(2)
+    merged = np.zeros_like(full.image_buffer)
+    lay = TileLayout(37, 23, 32, 32, 5)
+    assert lay.n_tiles == 2
+    for rank in range(5):
+        r = Renderer(sc, cfg); r.set_tiles(32, 32, rank, 5); r.sample(2)
+        ib = r.image_buffer
+        if rank >= 2:
+            assert np.all(ib == 0) and r.counters().samples == 0
+        lay.unpack_into(merged, lay.pack(ib, rank), rank)
+        r.close()
+    assert np.array_equal(bits(merged), bits(full.image_buffer))
+    with pytest.raises(RtpbrError):
+        g.set_scene(Scene(objs + objs[:1], False, sc.camera))          # 33 objects > RTPBR_MAX_OBJECTS
