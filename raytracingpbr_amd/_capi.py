@@ -15,7 +15,8 @@ from .config import Config
 from .dataclass import Camera, Counters, SDFObject
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "librtpbr_hip.so")
+# RTPBR_HIP_LIB overrides the path (A/B of differently built HIP libraries); it must still be a HIP build
+HIP_LIB_PATH = os.environ.get("RTPBR_HIP_LIB") or os.path.join(_HERE, "csrc", "librtpbr_hip.so")
 
 # every symbol include/rtpbr.h declares (checked by tests/test_capi_symbols.py)
 ENTRY_POINTS = [

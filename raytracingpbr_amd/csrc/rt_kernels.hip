@@ -264,8 +264,11 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
 enum { SL_EMPTY = 0, SL_READY = 1, SL_HIT = 2, SL_MISS = 3 };
 enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
 
+#ifndef RT_POOL_WAVES
+#define RT_POOL_WAVES 5   // Cornell pool kernel: 96 VGPRs (17 cold spills) -> 5 waves/SIMD, +1.5 % over 4
+#endif
 template <int KIND, int NOBJ>
-__global__ void __launch_bounds__(256) trace_paths_pool(const Params P) {
+__global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1)) trace_paths_pool(const Params P) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
     __shared__ uint32_t pool_all[4][F_COUNT][64];
     __shared__ uint32_t sstate_all[4][64];
