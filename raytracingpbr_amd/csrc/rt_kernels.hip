@@ -265,7 +265,7 @@ enum { SL_EMPTY = 0, SL_READY = 1, SL_HIT = 2, SL_MISS = 3 };
 enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
 
 #ifndef RT_POOL_WAVES
-#define RT_POOL_WAVES 5   // Cornell pool kernel: 96 VGPRs (17 cold spills) -> 5 waves/SIMD, +1.5 % over 4
+#define RT_POOL_WAVES 1   // 5 (96 VGPRs, 17 spills) measured +1.5 % but adds 8 GB of scratch traffic per launch: not worth it
 #endif
 template <int KIND, int NOBJ>
 __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1)) trace_paths_pool(const Params P) {
