@@ -254,6 +254,74 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Shared by both pool kernels: the wave-private LDS ray pool and the rank-matched swap.
+enum { SL_EMPTY = 0, SL_READY = 1, SL_HIT = 2, SL_MISS = 3 };
+constexpr int POOL_WORDS = 15;   // dwords per parked record; what they mean is the kernel's business
+
+struct PoolView {
+    uint32_t (*pool)[64];   // [word][slot]: lane s <-> slot s accesses are conflict-free
+    uint32_t* sstate;       // slot state, SL_*
+    uint32_t* tbl;          // rank -> slot table for the matching
+};
+
+RT_D int wave_rank(unsigned long long m) {   // number of set bits below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+RT_D void pool_load(const PoolView& V, uint32_t slot, uint32_t (&rec)[POOL_WORDS]) {
+#pragma unroll
+    for (int w = 0; w < POOL_WORDS; w++) rec[w] = V.pool[w][slot];
+}
+RT_D void pool_store(const PoolView& V, uint32_t slot, const uint32_t (&rec)[POOL_WORDS]) {
+#pragma unroll
+    for (int w = 0; w < POOL_WORDS; w++) V.pool[w][slot] = rec[w];
+}
+
+// Swap finished lanes with parked READY records (wave-uniform control flow; all lanes call it).
+//   is_done: this lane holds a finished record in rec[] that must be parked as `done_state`;
+//   is_idle: this lane holds nothing and wants a READY record.
+// Finished lanes are served first (they need ANY non-occupied slot: READY ones are swapped, free
+// ones just receive the record), then idle lanes take the remaining READY records.  The j-th
+// requester gets the j-th listed slot: both sides are ranked with ballot + mbcnt prefix counts and
+// matched through the 64-entry table.  Returns bit 0 = rec[] now holds a taken READY record,
+// bit 1 = this lane's record was parked.  m_ready / m_shade are refreshed from the slot states.
+RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint32_t done_state,
+                   uint32_t (&rec)[POOL_WORDS], unsigned long long& m_ready, unsigned long long& m_shade) {
+    const unsigned long long done = __ballot(is_done);
+    const unsigned long long idle = __ballot(is_idle);
+    const int n_done = __popcll(done);
+    const int n_ready = __popcll(m_ready);
+    if (!(n_done > 0 || (idle != 0 && n_ready > 0))) return 0;
+    const unsigned long long m_free = ~(m_ready | m_shade);
+    const int n_free = __popcll(m_free);
+    // slot side: READY slots first, then free slots, listed by rank
+    if ((m_ready >> lane) & 1ull) V.tbl[wave_rank(m_ready)] = (uint32_t)lane;
+    else if ((m_free >> lane) & 1ull) V.tbl[n_ready + wave_rank(m_free)] = (uint32_t)lane;
+    // lane side: finished lanes first, then idle lanes
+    const int req = is_done ? wave_rank(done) : n_done + wave_rank(idle);
+    const bool served = (is_done || is_idle) && req < n_ready + n_free;
+    const bool takes = served && req < n_ready;
+    const bool parks = served && is_done;
+    uint32_t slot = 0;
+    if (served) slot = V.tbl[req];
+    uint32_t got[POOL_WORDS];
+#pragma unroll
+    for (int w = 0; w < POOL_WORDS; w++) got[w] = rec[w];
+    if (takes) pool_load(V, slot, got);          // read the READY record before overwriting its slot
+    if (parks) {
+        pool_store(V, slot, rec);
+        V.sstate[slot] = done_state;
+    } else if (takes) {
+        V.sstate[slot] = SL_EMPTY;
+    }
+#pragma unroll
+    for (int w = 0; w < POOL_WORDS; w++) rec[w] = got[w];
+    const uint32_t st = V.sstate[lane];
+    m_ready = __ballot(st == SL_READY);
+    m_shade = __ballot(st == SL_HIT || st == SL_MISS);
+    return (takes ? 1 : 0) | (parks ? 2 : 0);
+}
+
+// -------------------------------------------------------------------------------------------
 // Scheduler 1: per-wave LDS ray pool ("parked rays").  Every wave owns 64 register lanes (the
 // rays being marched) plus 64 LDS slots holding parked rays that are either READY to start a
 // raycast or waiting to be shaded (HIT / MISS).  A lane whose raycast finishes swaps its ray
@@ -261,8 +329,8 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
 // so the march loop stays (nearly) full; shading runs on the SLOTS (lane s <-> slot s) only when
 // >= shade_lanes of them wait, so it runs on (nearly) full waves too.  Slots freed by finished
 // samples are refilled with fresh pixel-samples.  Wave-private: no cross-wave synchronisation.
-enum { SL_EMPTY = 0, SL_READY = 1, SL_HIT = 2, SL_MISS = 3 };
 enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
+static_assert(F_COUNT == POOL_WORDS, "trace record must fill the pool record");
 
 #ifndef RT_POOL_WAVES
 #define RT_POOL_WAVES 1   // 5 (96 VGPRs, 17 spills) measured +1.5 % but adds 8 GB of scratch traffic per launch: not worth it
@@ -279,7 +347,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
     const int wave = threadIdx.x >> 6;
     uint32_t (*pool)[64] = pool_all[wave];
     uint32_t* sstate = sstate_all[wave];
-    uint32_t* tbl = tbl_all[wave];
+    const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
     sstate[lane] = SL_EMPTY;
 
     Lane L;
@@ -388,64 +456,24 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
 
         // ================================================================ dispatch: swap finished lanes with parked rays
         {
-            const unsigned long long done = __ballot(L.state == ST_HIT || L.state == ST_MISS);
-            const unsigned long long idle = __ballot(L.state == ST_IDLE);
-            const int n_done = __popcll(done);
-            const int n_ready = __popcll(m_ready);
-            if (n_done > 0 || (idle != 0 && n_ready > 0)) {
-                const unsigned long long m_free = ~(m_ready | m_shade);
-                const int n_free = __popcll(m_free);
-                auto rank_in = [](unsigned long long m) {
-                    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                };
-                // slot side: READY slots first, then free slots, listed by rank
-                const bool s_ready = (m_ready >> lane) & 1ull;
-                const bool s_free = (m_free >> lane) & 1ull;
-                if (s_ready) tbl[rank_in(m_ready)] = (uint32_t)lane;
-                else if (s_free) tbl[n_ready + rank_in(m_free)] = (uint32_t)lane;
-                // lane side: finished lanes first (they carry a ray that must be parked), then idle lanes
-                const bool is_done = (done >> lane) & 1ull;
-                const bool is_idle = (idle >> lane) & 1ull;
-                const int req = is_done ? rank_in(done) : n_done + rank_in(idle);
-                const bool served = (is_done || is_idle) && req < n_ready + n_free;
-                const bool takes = served && req < n_ready;          // gets a READY ray
-                const bool parks = served && is_done;                // leaves its finished ray in the slot
-                uint32_t slot = 0;
-                if (served) slot = tbl[req];
-                vec3 no = L.o, nd = L.d, ncol = a_col;
-                int nbounce = a_bounce;
-                uint32_t nkey = a_key, ncnt = a_cnt, nitem = a_item;
-                if (takes) {
-                    no = mk(u2f(pool[F_OX][slot]), u2f(pool[F_OY][slot]), u2f(pool[F_OZ][slot]));
-                    nd = mk(u2f(pool[F_DX][slot]), u2f(pool[F_DY][slot]), u2f(pool[F_DZ][slot]));
-                    ncol = mk(u2f(pool[F_CR][slot]), u2f(pool[F_CG][slot]), u2f(pool[F_CB][slot]));
-                    nbounce = (int)pool[F_BOUNCE][slot];
-                    nkey = pool[F_KEY][slot];
-                    ncnt = pool[F_CNT][slot];
-                    nitem = pool[F_ITEM][slot];
-                }
-                if (parks) {
-                    pool[F_OX][slot] = f2u(L.o.x); pool[F_OY][slot] = f2u(L.o.y); pool[F_OZ][slot] = f2u(L.o.z);
-                    pool[F_DX][slot] = f2u(L.d.x); pool[F_DY][slot] = f2u(L.d.y); pool[F_DZ][slot] = f2u(L.d.z);
-                    pool[F_CR][slot] = f2u(a_col.x); pool[F_CG][slot] = f2u(a_col.y); pool[F_CB][slot] = f2u(a_col.z);
-                    pool[F_TEVAL][slot] = f2u(L.t_eval);
-                    pool[F_IDX][slot] = (uint32_t)L.idx;
-                    pool[F_BOUNCE][slot] = (uint32_t)a_bounce;
-                    pool[F_KEY][slot] = a_key;
-                    pool[F_CNT][slot] = a_cnt;
-                    pool[F_ITEM][slot] = a_item;
-                    sstate[slot] = L.state == ST_HIT ? SL_HIT : SL_MISS;
-                } else if (takes) {
-                    sstate[slot] = SL_EMPTY;
-                }
-                if (parks) L.state = ST_IDLE;
-                if (takes) {
-                    L.o = no; L.d = nd; a_col = ncol; a_bounce = nbounce; a_key = nkey; a_cnt = ncnt; a_item = nitem;
-                    march_init(P, L);
-                }
-                const uint32_t st = sstate[lane];
-                m_ready = __ballot(st == SL_READY);
-                m_shade = __ballot(st == SL_HIT || st == SL_MISS);
+            const bool is_done = L.state == ST_HIT || L.state == ST_MISS;
+            uint32_t rec[POOL_WORDS];
+            rec[F_OX] = f2u(L.o.x); rec[F_OY] = f2u(L.o.y); rec[F_OZ] = f2u(L.o.z);
+            rec[F_DX] = f2u(L.d.x); rec[F_DY] = f2u(L.d.y); rec[F_DZ] = f2u(L.d.z);
+            rec[F_CR] = f2u(a_col.x); rec[F_CG] = f2u(a_col.y); rec[F_CB] = f2u(a_col.z);
+            rec[F_TEVAL] = f2u(L.t_eval);
+            rec[F_IDX] = (uint32_t)L.idx;
+            rec[F_BOUNCE] = (uint32_t)a_bounce;
+            rec[F_KEY] = a_key; rec[F_CNT] = a_cnt; rec[F_ITEM] = a_item;
+            const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
+            if (r & 2) L.state = ST_IDLE;
+            if (r & 1) {
+                L.o = mk(u2f(rec[F_OX]), u2f(rec[F_OY]), u2f(rec[F_OZ]));
+                L.d = mk(u2f(rec[F_DX]), u2f(rec[F_DY]), u2f(rec[F_DZ]));
+                a_col = mk(u2f(rec[F_CR]), u2f(rec[F_CG]), u2f(rec[F_CB]));
+                a_bounce = (int)rec[F_BOUNCE];
+                a_key = rec[F_KEY]; a_cnt = rec[F_CNT]; a_item = rec[F_ITEM];
+                march_init(P, L);
             }
         }
 
@@ -635,6 +663,7 @@ __global__ void __launch_bounds__(256) persistent_steps(const Params P, int step
 // to march, exactly like trace_paths_pool.  A pixel is owned by one context for the whole launch,
 // so its deposits into image_buffer happen in step order (bit-exact with the sequential form).
 enum { G_OX = 0, G_OY, G_OZ, G_DX, G_DY, G_DZ, G_CR, G_CG, G_CB, G_DEPTH, G_IDX, G_Q, G_S, G_KEY, G_CNT, G_COUNT };
+static_assert(G_COUNT == POOL_WORDS, "pixel-context record must fill the pool record");
 
 struct PixCtx {
     vec3 o, d, col;
@@ -725,7 +754,7 @@ __global__ void __launch_bounds__(256) persistent_pool(const Params P, int steps
     const int wave = threadIdx.x >> 6;
     uint32_t (*pool)[64] = pool_all[wave];
     uint32_t* sstate = sstate_all[wave];
-    uint32_t* tbl = tbl_all[wave];
+    const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
     sstate[lane] = SL_EMPTY;
 
     Lane L;
@@ -842,65 +871,29 @@ __global__ void __launch_bounds__(256) persistent_pool(const Params P, int steps
             }
         }
 
-        // ================================================================ dispatch (as in trace_paths_pool)
+        // ================================================================ dispatch (pool_swap, as in trace_paths_pool)
         {
-            const unsigned long long done = __ballot(L.state == ST_HIT || L.state == ST_MISS);
-            const unsigned long long idle = __ballot(L.state == ST_IDLE);
-            const int n_done = __popcll(done);
-            const int n_ready = __popcll(m_ready);
-            if (n_done > 0 || (idle != 0 && n_ready > 0)) {
-                const unsigned long long m_free = ~(m_ready | m_shade);
-                const int n_free = __popcll(m_free);
-                auto rank_in = [](unsigned long long m) {
-                    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                };
-                const bool s_ready = (m_ready >> lane) & 1ull;
-                const bool s_free = (m_free >> lane) & 1ull;
-                if (s_ready) tbl[rank_in(m_ready)] = (uint32_t)lane;
-                else if (s_free) tbl[n_ready + rank_in(m_free)] = (uint32_t)lane;
-                const bool is_done = (done >> lane) & 1ull;
-                const bool is_idle = (idle >> lane) & 1ull;
-                const int req = is_done ? rank_in(done) : n_done + rank_in(idle);
-                const bool served = (is_done || is_idle) && req < n_ready + n_free;
-                const bool takes = served && req < n_ready;
-                const bool parks = served && is_done;
-                uint32_t slot = 0;
-                if (served) slot = tbl[req];
-                vec3 no = L.o, nd = L.d, ncol = a_col;
-                int ndepth = a_depth, ns = a_s;
-                uint32_t nq = a_q, nkey = a_key, ncnt = a_cnt;
-                if (takes) {
-                    no = mk(u2f(pool[G_OX][slot]), u2f(pool[G_OY][slot]), u2f(pool[G_OZ][slot]));
-                    nd = mk(u2f(pool[G_DX][slot]), u2f(pool[G_DY][slot]), u2f(pool[G_DZ][slot]));
-                    ncol = mk(u2f(pool[G_CR][slot]), u2f(pool[G_CG][slot]), u2f(pool[G_CB][slot]));
-                    ndepth = (int)pool[G_DEPTH][slot];
-                    nq = pool[G_Q][slot];
-                    ns = (int)pool[G_S][slot];
-                    nkey = pool[G_KEY][slot];
-                    ncnt = pool[G_CNT][slot];
-                }
-                if (parks) {
-                    pool[G_OX][slot] = f2u(L.o.x); pool[G_OY][slot] = f2u(L.o.y); pool[G_OZ][slot] = f2u(L.o.z);
-                    pool[G_DX][slot] = f2u(L.d.x); pool[G_DY][slot] = f2u(L.d.y); pool[G_DZ][slot] = f2u(L.d.z);
-                    pool[G_CR][slot] = f2u(a_col.x); pool[G_CG][slot] = f2u(a_col.y); pool[G_CB][slot] = f2u(a_col.z);
-                    pool[G_DEPTH][slot] = (uint32_t)a_depth;
-                    pool[G_IDX][slot] = (uint32_t)L.idx;
-                    pool[G_Q][slot] = a_q;
-                    pool[G_S][slot] = (uint32_t)a_s;
-                    pool[G_KEY][slot] = a_key;
-                    pool[G_CNT][slot] = a_cnt;
-                    sstate[slot] = L.state == ST_HIT ? SL_HIT : SL_MISS;
-                } else if (takes) {
-                    sstate[slot] = SL_EMPTY;
-                }
-                if (parks) L.state = ST_IDLE;
-                if (takes) {
-                    L.o = no; L.d = nd; a_col = ncol; a_depth = ndepth; a_q = nq; a_s = ns; a_key = nkey; a_cnt = ncnt;
-                    src_march_init(L);
-                }
-                const uint32_t st = sstate[lane];
-                m_ready = __ballot(st == SL_READY);
-                m_shade = __ballot(st == SL_HIT || st == SL_MISS);
+            const bool is_done = L.state == ST_HIT || L.state == ST_MISS;
+            uint32_t rec[POOL_WORDS];
+            rec[G_OX] = f2u(L.o.x); rec[G_OY] = f2u(L.o.y); rec[G_OZ] = f2u(L.o.z);
+            rec[G_DX] = f2u(L.d.x); rec[G_DY] = f2u(L.d.y); rec[G_DZ] = f2u(L.d.z);
+            rec[G_CR] = f2u(a_col.x); rec[G_CG] = f2u(a_col.y); rec[G_CB] = f2u(a_col.z);
+            rec[G_DEPTH] = (uint32_t)a_depth;
+            rec[G_IDX] = (uint32_t)L.idx;
+            rec[G_Q] = a_q;
+            rec[G_S] = (uint32_t)a_s;
+            rec[G_KEY] = a_key; rec[G_CNT] = a_cnt;
+            const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
+            if (r & 2) L.state = ST_IDLE;
+            if (r & 1) {
+                L.o = mk(u2f(rec[G_OX]), u2f(rec[G_OY]), u2f(rec[G_OZ]));
+                L.d = mk(u2f(rec[G_DX]), u2f(rec[G_DY]), u2f(rec[G_DZ]));
+                a_col = mk(u2f(rec[G_CR]), u2f(rec[G_CG]), u2f(rec[G_CB]));
+                a_depth = (int)rec[G_DEPTH];
+                a_q = rec[G_Q];
+                a_s = (int)rec[G_S];
+                a_key = rec[G_KEY]; a_cnt = rec[G_CNT];
+                src_march_init(L);
             }
         }
 
