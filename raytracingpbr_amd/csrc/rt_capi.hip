@@ -25,7 +25,8 @@ void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
 void launch_unpack(const Params& P, const float4* src, hipStream_t st);
 void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st);
-int trace_blocks_per_cu(int kind, int n_obj, int scheduler);
+int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
+void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 }  // namespace rt
 
@@ -66,6 +67,11 @@ struct rtpbr_ctx {
     float* bunny = nullptr;
     float4* stage = nullptr;
     size_t stage_cap = 0;  // bytes
+    float2* primary = nullptr;
+    size_t primary_cap = 0;
+    int primary_split = 1;
+    int specialize = 1;      // use the RT_BOX_SIGNATURES instance the scene fits
+    uint32_t scene_sig = 0;
     unsigned int* work_counter = nullptr;
     Counters* counters = nullptr;
     // tiles
@@ -74,7 +80,7 @@ struct rtpbr_ctx {
     uint32_t sample_base = 0;
     unsigned long long deposits_host = 0;
     // options
-    long long staging_bytes = 10LL << 30;  // 288 GB of HBM: stage a whole 1080p x 256 spp step (8.5 GB) in one launch
+    long long staging_bytes = 16LL << 30;  // 288 GB of HBM: a whole 1080p x 256 spp step (8.5 GB of samples + 4.2 GB of primary records) is one launch
     int wait_lanes = 24;
     int shade_lanes = 56;
     int swap_lanes = 8;
@@ -133,6 +139,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->env);
     (void)hipFree(c->bunny);
     (void)hipFree(c->stage);
+    (void)hipFree(c->primary);
     (void)hipFree(c->work_counter);
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -223,6 +230,19 @@ static void rotate(const float* rad, float* m) {
     m3_mul(t, rx, m);
 }
 
+// exact sparsity pattern of a world->local matrix (see to_local): 0 entries must be +-0, the axis entry 1.0f
+static int rotation_class(const float* m) {
+    auto z = [&](int i) { return m[i] == 0.0f; };
+    auto one = [&](int i) { return m[i] == 1.0f; };
+    for (int i = 0; i < 9; i++)
+        if (!std::isfinite(m[i])) return ROT_GENERAL;
+    if (one(0) && one(4) && one(8) && z(1) && z(2) && z(3) && z(5) && z(6) && z(7)) return ROT_IDENT;
+    if (one(0) && z(1) && z(2) && z(3) && z(6)) return ROT_X;
+    if (one(4) && z(1) && z(3) && z(5) && z(7)) return ROT_Y;
+    if (one(8) && z(2) && z(5) && z(6) && z(7)) return ROT_Z;
+    return ROT_GENERAL;
+}
+
 extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, int scale10) {
     if (!c || !objs) return fail(RTPBR_EINVAL, "null argument");
     if (n <= 0 || n > MAX_OBJ) return fail(RTPBR_EINVAL, "object count must be 1..32");
@@ -255,6 +275,29 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
         if (m.type != RTPBR_SHAPE_BUNNY) all_bunny = false;
         else any_bunny = true;
         if (m.type < RTPBR_SHAPE_NONE || m.type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
+    }
+    c->scene_sig = 0;
+    if (all_box && n == 8) {
+        // first listed signature whose every specialised class fits the object's matrix
+        // (an identity matrix fits every single-axis class)
+        int cls[8];
+        for (int i = 0; i < 8; i++) cls[i] = rotation_class(c->P.objm[i].m);
+        const uint32_t sigs[] = {
+#define RT_SIG_ITEM(sig, ...) sig,
+            RT_BOX_SIGNATURES(RT_SIG_ITEM, 0)
+#undef RT_SIG_ITEM
+        };
+        for (uint32_t sig : sigs) {
+            bool ok = true;
+            for (int i = 0; i < 8 && ok; i++) {
+                const int want = (int)((sig >> (3 * i)) & 7u);
+                ok = want == ROT_GENERAL || want == cls[i] || (cls[i] == ROT_IDENT && want != ROT_IDENT);
+            }
+            if (ok) {
+                c->scene_sig = sig;
+                break;
+            }
+        }
     }
     c->n_obj = n;
     c->P.n_obj = n;
@@ -369,7 +412,7 @@ static hipEvent_t next_event(rtpbr_ctx* c) {
 }
 
 static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
-    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->scheduler < 0 ? 1 : c->scheduler);
+    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->P.box_sig, c->scheduler < 0 ? 1 : c->scheduler);
     if (per_cu <= 0) per_cu = 2;
     if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
     long long grid = (long long)per_cu * c->n_cu;
@@ -402,6 +445,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_mfma = c->mlp_mfma;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
+    P.box_sig = c->specialize ? c->scene_sig : 0;
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
@@ -448,14 +492,15 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     } else {
         int left = n;
         while (left > 0) {
-            long long per_spp = (long long)P.np * (long long)sizeof(float4);
+            const bool split = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
+            long long per_spp = (long long)P.np * (long long)(sizeof(float4) + (split ? sizeof(float2) : 0));
             long long kmax = c->staging_bytes / per_spp;
             if (kmax < 1) kmax = 1;
             // keep total_items within 32 bits
             long long k32 = 0xFFFFFFFFLL / (long long)P.np - 1;
             if (kmax > k32) kmax = k32;
             int K = (int)(left < kmax ? left : kmax);
-            size_t need = (size_t)per_spp * (size_t)K;
+            size_t need = (size_t)P.np * (size_t)K * sizeof(float4);
             if (need > c->stage_cap) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 (void)hipFree(c->stage);
@@ -464,6 +509,19 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 HIP_TRY(hipMalloc(&c->stage, need));
                 c->stage_cap = need;
             }
+            if (split) {
+                size_t pneed = (size_t)P.np * (size_t)K * sizeof(float2);
+                if (pneed > c->primary_cap) {
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    (void)hipFree(c->primary);
+                    c->primary = nullptr;
+                    c->primary_cap = 0;
+                    HIP_TRY(hipMalloc(&c->primary, pneed));
+                    c->primary_cap = pneed;
+                }
+            }
+            P.primary = c->primary;
+            P.primary_split = split ? 1 : 0;
             P.stage = c->stage;
             P.K = K;
             P.sample_base = c->sample_base;
@@ -477,6 +535,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
             hipEvent_t a = next_event(c), b = next_event(c);
             HIP_TRY(hipEventRecord(a, c->stream));
+            if (split) launch_primary(P, c->kind, c->n_cu, c->stream);
             launch_trace(P, c->kind, grid, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
             launch_accumulate(P, c->stream);
@@ -636,6 +695,12 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "primary_split")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "primary_split must be 0 or 1");
+        c->primary_split = (int)value;
+    } else if (!strcmp(key, "specialize")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "specialize must be 0 or 1");
+        c->specialize = (int)value;
     } else if (!strcmp(key, "mlp_mfma")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "mlp_mfma must be 0 or 1");
         c->mlp_mfma = (int)value;

@@ -6,6 +6,7 @@
 // whose behaviour it reproduces; arithmetic follows rt_math.hpp (exact ops, fixed order).
 #pragma once
 #include <cstddef>
+#include <type_traits>
 
 #include "rt_types.hpp"
 
@@ -243,8 +244,19 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
 
 // F9 world -> local (src/sdf.py:64-68) + the bunny's per-frame animation (bunny_sdf_glass.py:213-217)
 template <int KIND, typename OBJ>
-RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p) {
+RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL) {
     vec3 d = p - mk(o.px, o.py, o.pz);
+    if constexpr (KIND == KIND_BOXES) {
+        // Sparse rotations.  `cls` is a COMPILE-TIME constant after unrolling (rotation signature of
+        // the scene, see nearest); matrices whose off-axis entries are EXACTLY 0 and whose axis
+        // entry is EXACTLY 1 (rotation about one coordinate axis, or none) are classified by
+        // rtpbr_set_scene.  Dropping the x*0 and x*1 terms of the fma chain is exact for finite
+        // positions up to the sign of a zero result, and the box SDF only sees |l|.
+        if (cls == ROT_IDENT) return d;
+        if (cls == ROT_X) return mk(d.x, fma_(o.m[5], d.z, o.m[4] * d.y), fma_(o.m[8], d.z, o.m[7] * d.y));
+        if (cls == ROT_Y) return mk(fma_(o.m[2], d.z, o.m[0] * d.x), d.y, fma_(o.m[8], d.z, o.m[6] * d.x));
+        if (cls == ROT_Z) return mk(fma_(o.m[1], d.y, o.m[0] * d.x), fma_(o.m[4], d.y, o.m[3] * d.x), d.z);
+    }
     vec3 l = mulv(o.m, d);
     if (KIND == KIND_BUNNY || (KIND == KIND_MIXED && o.type == RTPBR_SHAPE_BUNNY)) {
         float st = P.anim_s, ct = P.anim_c;
@@ -256,8 +268,8 @@ RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p) {
 }
 
 template <int KIND, typename OBJ>
-RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p) {
-    return sdf_local<KIND>(P, o.type, to_local<KIND>(P, o, p), o.sx, o.sy, o.sz);
+RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL) {
+    return sdf_local<KIND>(P, o.type, to_local<KIND>(P, o, p, cls), o.sx, o.sy, o.sz);
 }
 
 // ---------------------------------------------------------------- F8 nearest
@@ -279,7 +291,9 @@ typedef const ObjM* ObjTab;   // host pass only parses the device functions
 RT_D ObjTab obj_table() { return nullptr; }
 #endif
 
-template <int KIND, int NOBJ>
+// rotation class of object i in the kernel's compile-time signature (3 bits per object, 0 = general)
+#define RT_SIG_CLS(i) (int)((SIG >> (3 * (i))) & 7u)
+template <int KIND, int NOBJ, uint32_t SIG = 0>
 RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
     const int n = NOBJ > 0 ? NOBJ : P.n_obj;
     ObjTab tab = obj_table();
@@ -302,13 +316,13 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
             const ObjM oa = tab[i];
             const ObjM ob = tab[i + 1 < NOBJ ? i + 1 : i];
             if (i >= start) {
-                float d = fabs_(signed_distance<KIND>(P, oa, p));
+                float d = fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i : idx;
             }
             if (i + 1 < NOBJ) {
-                float d = fabs_(signed_distance<KIND>(P, ob, p));
+                float d = fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i + 1 : idx;
@@ -322,6 +336,41 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
             best = lt ? d : best;
             idx = lt ? i : idx;
         }
+    }
+}
+
+// ---------------------------------------------------------------- F8 nearest with wave-level culling
+// For COHERENT waves (the 64 lanes march almost the same ray: consecutive samples of one pixel)
+// most objects are far from every lane, and exact bounds prove it without evaluating them.
+// |sdf_i| is 1-Lipschitz in the position, so with `moved` = distance marched since the last step:
+//   lb_i = (last exact |sdf_i|) - (everything marched since)     is a lower bound of |sdf_i| now,
+//   ub   = (last exact minimum) + moved                          is an upper bound of the new minimum.
+// Object i is skipped when lb_i > ub for EVERY lane (wave-uniform branch): then |sdf_i| > min strictly,
+// so it is neither the nearest nor a tie and (index, distance) are exactly what the full loop gives.
+// Objects are still visited in index order with the strict `<` of the reference, so ties resolve
+// identically.  eps covers the rounding of the computed distances (|error| <~ 10 ulp(|pos|); we
+// allow 2^-19 (t + 64) on each side).  lb[] and ub are maintained by the caller across steps.
+template <int KIND, int NOBJ, uint32_t SIG = 0>
+RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub, float (&lb)[NOBJ > 0 ? NOBJ : 1],
+                         int& idx, float& best) {
+    static_assert(NOBJ > 0, "culling needs a compile-time object count");
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    const float eps = 1.9073486328125e-06f * (fabs_(t) + 64.0f);
+    const float bound = ub + eps;
+    best = P.cfg.max_dis;   // the reference starts from object 0 or from MAX_DIS (nearest_init); see below
+    idx = 0;
+    bool first = !P.cfg.nearest_init;
+#pragma unroll
+    for (int i = 0; i < NOBJ; i++) {
+        if (__all(!active || lb[i] > bound)) continue;            // provably not the nearest for any lane
+        const ObjM o = tab[i];
+        float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i)));
+        lb[i] = d - eps;
+        bool take = first || d < best;                            // nearest_init = 0: the first visited object initialises
+        best = take ? d : best;
+        idx = take ? i : idx;
+        first = false;
     }
 }
 
@@ -396,13 +445,13 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
     if (done) L.state = hit ? ST_HIT : ST_MISS;
 }
 
-template <int KIND, int NOBJ>
+template <int KIND, int NOBJ, uint32_t SIG = 0>
 RT_D void march_step(const Params& P, Lane& L) {
     vec3 pos = fma3(L.t, L.d, L.o);
     L.t_eval = L.t;
     int idx;
     float dist;
-    nearest<KIND, NOBJ>(P, pos, idx, dist);
+    nearest<KIND, NOBJ, SIG>(P, pos, idx, dist);
     march_update(P, L, idx, dist);
 }
 

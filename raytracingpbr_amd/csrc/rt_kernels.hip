@@ -175,7 +175,7 @@ RT_D bool claim_items(const Params& P, WorkRange& wr, bool want, int lane, uint3
 
 // -------------------------------------------------------------------------------------------
 // Scheduler 0: in-register refill (no LDS ray pool).
-template <int KIND, int NOBJ>
+template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256) trace_paths(const Params P) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
     stage_objects(P, lds_obj);
@@ -246,11 +246,86 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
         kstar = (wr.drained && kstar > cap) ? cap : kstar;
         int n_march;
         do {
-            if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+            if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
             n_march = __popcll(__ballot(L.state == ST_MARCH));
         } while (n_march > 0 && (n_active - n_march) < kstar);
     }
     flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, 0);
+}
+
+// -------------------------------------------------------------------------------------------
+// Primary raycasts in their own kernel (option primary_split).  A wave takes 64 CONSECUTIVE work
+// items = consecutive samples of one pixel, so its 64 camera rays differ only by the sub-pixel
+// jitter and the lens offset: they march in lock step (no pool needed, nearly no divergence) and
+// the object loop can be culled at wave level (nearest_culled).  The result of the raycast —
+// {t_eval, nearest index, hit/miss} — is written per item and the pool kernel resumes the path
+// from there (it regenerates the camera ray from the same RNG stream: cheaper than moving 24 more
+// bytes per sample).  Same arithmetic as the pool kernel's march, bit-identical results.
+template <int KIND, int NOBJ, uint32_t SIG = 0>
+__global__ void __launch_bounds__(256) primary_rays(const Params P) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_groups = (P.total_items + 63u) / 64u;
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t n_steps = 0, n_raycasts = 0;
+    // persistent waves, grid-stride over groups of 64 consecutive items (a few thousand resident
+    // blocks; one block per 256 items would be dispatch-bound: 2 M blocks of ~10 us each)
+    for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_groups; g += n_waves) {
+        const uint32_t item = g * 64u + (uint32_t)lane;
+        Lane L;
+        L.state = ST_IDLE;
+        L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
+        L.o = L.d = mk(0, 0, 0);
+        L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
+        L.idx = 0;
+        L.steps_left = 0;
+        PathRay R;
+        R.item = item;
+        bool valid = false;
+        if (item < P.total_items) {
+            int r = start_item(P, R);
+            valid = r == 1;
+            if (valid) {
+                L.o = R.o;
+                L.d = R.d;
+                march_init(P, L);
+            }
+        }
+        if constexpr (NOBJ > 0 && KIND == KIND_BOXES) {
+            float lb[NOBJ > 0 ? NOBJ : 1];
+#pragma unroll
+            for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] = -1.0f;   // nothing known yet: everything is evaluated
+            float ub = 3.0e38f;
+            while (__any(L.state == ST_MARCH)) {
+                const bool active = L.state == ST_MARCH;
+                vec3 pos = fma3(L.t, L.d, L.o);
+                const float t_before = L.t;
+                int idx;
+                float dist;
+                // all lanes run the (wave-uniform) object loop; finished lanes just do not commit
+                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist);
+                if (active) {
+                    L.t_eval = L.t;
+                    march_update(P, L, idx, dist);
+                }
+                // the next evaluation point is |dt| * |d| away; |d| <= 1 + 2^-20
+                const float moved = fabs_(L.t - t_before) * 1.000001f;
+                ub = dist + moved;
+#pragma unroll
+                for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
+            }
+        } else {
+            while (__any(L.state == ST_MARCH)) {
+                if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
+            }
+        }
+        if (item < P.total_items) {
+            uint32_t code = (uint32_t)L.idx | ((uint32_t)(valid ? L.state : ST_IDLE) << 8);
+            P.primary[item] = make_float2(L.t_eval, __builtin_bit_cast(float, code));
+        }
+        n_steps += L.n_steps;
+        n_raycasts += L.n_raycasts;
+    }
+    flush_counters(P, n_steps, n_raycasts, 0, 0, 0, 0);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -335,7 +410,7 @@ static_assert(F_COUNT == POOL_WORDS, "trace record must fill the pool record");
 #ifndef RT_POOL_WAVES
 #define RT_POOL_WAVES 1   // 5 (96 VGPRs, 17 spills) measured +1.5 % but adds 8 GB of scratch traffic per launch: not worth it
 #endif
-template <int KIND, int NOBJ>
+template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1)) trace_paths_pool(const Params P) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
     __shared__ uint32_t pool_all[4][F_COUNT][64];
@@ -432,11 +507,34 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                 }
                 // refill free slots with fresh pixel-samples
                 bool got = claim_items(P, wr, st == SL_EMPTY && !alive, lane, R.item);
+                uint32_t resumed = 0;   // primary_split: state the primary kernel left this item in
                 if (got) {
                     int r = start_item(P, R);
-                    if (r == 1) alive = true;
-                    else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
+                    if (r == 1) {
+                        if (P.primary_split) {
+                            const float2 rec = P.primary[R.item];
+                            const uint32_t code = __builtin_bit_cast(uint32_t, rec.y);
+                            R.t_eval = rec.x;
+                            R.idx = (int)(code & 0xffu);
+                            resumed = code >> 8;                 // ST_HIT or ST_MISS
+                        } else {
+                            alive = true;
+                        }
+                    } else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
                     else write_sample(P, R.item, mk(0, 0, 0), 0.0f);
+                }
+                if (resumed == ST_HIT || resumed == ST_MISS) {
+                    // park the finished primary raycast; it is shaded with the next batch
+                    pool[F_OX][lane] = f2u(R.o.x); pool[F_OY][lane] = f2u(R.o.y); pool[F_OZ][lane] = f2u(R.o.z);
+                    pool[F_DX][lane] = f2u(R.d.x); pool[F_DY][lane] = f2u(R.d.y); pool[F_DZ][lane] = f2u(R.d.z);
+                    pool[F_CR][lane] = f2u(R.col.x); pool[F_CG][lane] = f2u(R.col.y); pool[F_CB][lane] = f2u(R.col.z);
+                    pool[F_TEVAL][lane] = f2u(R.t_eval);
+                    pool[F_IDX][lane] = (uint32_t)R.idx;
+                    pool[F_BOUNCE][lane] = (uint32_t)R.bounce;
+                    pool[F_KEY][lane] = R.key;
+                    pool[F_CNT][lane] = R.cnt;
+                    pool[F_ITEM][lane] = R.item;
+                    st = resumed == ST_HIT ? SL_HIT : SL_MISS;
                 }
                 if (alive) {
                     pool[F_OX][lane] = f2u(R.o.x); pool[F_OY][lane] = f2u(R.o.y); pool[F_OZ][lane] = f2u(R.o.z);
@@ -450,7 +548,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                 }
                 sstate[lane] = st;
                 m_ready = __ballot(st == SL_READY);
-                m_shade = 0;
+                m_shade = __ballot(st == SL_HIT || st == SL_MISS);   // non-zero only with primary_split
             }
         }
 
@@ -512,7 +610,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                         }
                     }
                 } else {
-                    if (L.state == ST_MARCH) march_step<KIND, NOBJ>(P, L);
+                    if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
                 }
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
                 n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
@@ -1004,9 +1102,13 @@ __global__ void sqrt_exhaustive(unsigned long long* mismatches) {
 }
 
 // ---- launchers used by rt_capi.hip -------------------------------------------------------
+#define RT_DISPATCH_SIG(sig, KERNEL, ...) \
+        else if (kind == KIND_BOXES && P.n_obj == 8 && P.box_sig == sig) { auto k = KERNEL<KIND_BOXES, 8, sig>; __VA_ARGS__; }
 #define RT_DISPATCH_KIND(KERNEL, ...)                                                       \
     do {                                                                                    \
-        if (kind == KIND_BOXES && P.n_obj == 8) { auto k = KERNEL<KIND_BOXES, 8>; __VA_ARGS__; }  \
+        if (false) {}                                                                       \
+        RT_BOX_SIGNATURES(RT_DISPATCH_SIG, KERNEL, __VA_ARGS__)                             \
+        else if (kind == KIND_BOXES && P.n_obj == 8) { auto k = KERNEL<KIND_BOXES, 8>; __VA_ARGS__; }  \
         else if (kind == KIND_BOXES) { auto k = KERNEL<KIND_BOXES, 0>; __VA_ARGS__; }        \
         else if (kind == KIND_BUNNY) { auto k = KERNEL<KIND_BUNNY, 0>; __VA_ARGS__; }        \
         else if (kind == KIND_MIXED) { auto k = KERNEL<KIND_MIXED, 0>; __VA_ARGS__; }        \
@@ -1017,11 +1119,19 @@ void launch_trace(const Params& P, int kind, int grid, hipStream_t st) {
     if (P.scheduler == 1) RT_DISPATCH_KIND(trace_paths_pool, hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, P));
     else RT_DISPATCH_KIND(trace_paths, hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, P));
 }
-int trace_blocks_per_cu(int kind, int n_obj, int scheduler) {
+void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st) {
+    long long need = ((long long)P.total_items + 255) / 256;
+    long long grid = (long long)n_cu * 8;            // 32 waves per CU: the kernel needs only ~40 VGPRs
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    RT_DISPATCH_KIND(primary_rays, hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), 0, st, P));
+}
+int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler) {
     int per_cu = 0;
     hipError_t e = hipSuccess;
     Params P;
     P.n_obj = n_obj;
+    P.box_sig = box_sig;
     if (scheduler == 1) RT_DISPATCH_KIND(trace_paths_pool, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     else RT_DISPATCH_KIND(trace_paths, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     return e == hipSuccess ? per_cu : 0;

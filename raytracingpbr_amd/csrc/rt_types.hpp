@@ -22,6 +22,17 @@ static_assert(sizeof(rtpbr_config) == 160 && sizeof(rtpbr_object) == 116 && size
                   sizeof(rtpbr_ray) == 40,
               "C-ABI struct layout changed");
 
+// Rotation class of an object's world->local matrix (to_local): a matrix whose off-axis entries are
+// exactly +-0 and whose axis entry is exactly 1 needs 4 of the 9 products of the general chain.
+enum { ROT_GENERAL = 0, ROT_IDENT = 1, ROT_X = 2, ROT_Y = 3, ROT_Z = 4 };
+// Rotation SIGNATURE of an 8-box scene: 3 bits per object.  The march kernels are additionally
+// instantiated ahead of time for the signatures listed here (the class of every object is then a
+// compile-time constant of the unrolled object loop: no branches).  rtpbr_set_scene picks the first
+// listed signature the scene is compatible with, else the general instance (signature 0).
+//   0x4db691: I X X Y Y Y Y X — a room of axis-aligned slabs (90-degree rotations about x or y) with
+//             yawed blocks inside, i.e. the Cornell Box layouts of the reference's examples
+#define RT_BOX_SIGNATURES(X, ...) X(0x4db691u, __VA_ARGS__)
+
 // 16 dwords: what one march step needs from one object
 struct ObjM {
     float px, py, pz;
@@ -78,6 +89,9 @@ struct Params {
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)
     // pointers
     float4* stage;
+    float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
+    int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
+    uint32_t box_sig;       // host side: which RT_BOX_SIGNATURES instance to launch (0 = general)
     float4* image_buffer;   // T7 (W,H) float4
     float* image_pixels;    // T8 (W,H,3)
     rtpbr_ray* ray_buffer;  // T6

@@ -135,18 +135,47 @@ def test_schedule_independence():
                  {"scheduler": 0, "wait_lanes": 7, "waves_per_cu": 4}, {"scheduler": 0},
                  {"scheduler": 1, "shade_lanes": 1, "swap_lanes": 1}, {"scheduler": 1, "shade_lanes": 64, "swap_lanes": 64},
                  {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
-                 {"staging_bytes": 1 << 20}, {"waves_per_cu": 1}):
+                 {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
+                 {"primary_split": 0}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
+                 {"primary_split": 1, "staging_bytes": 1 << 20, "shade_lanes": 3}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
         r.sample(12)
         assert np.array_equal(bits(r.image_buffer), want), opts
+        c0, c1 = ref.counters(), r.counters()
+        assert (c0.samples, c0.raycasts, c0.march_steps, c0.hits, c0.sky_lookups) == \
+               (c1.samples, c1.raycasts, c1.march_steps, c1.hits, c1.sky_lookups), opts
         r.close()
     r = Renderer(case.scene, case.cfg)
     for n in (1, 4, 7):
         r.sample(n)
     assert np.array_equal(bits(r.image_buffer), want)
     assert np.all(r.image_buffer[..., 3] == 12.0)
+
+
+@pytest.mark.parametrize("rots", ["axis_aligned", "mixed_axes", "tilted"])
+def test_rotation_signatures_match_oracle(rots):
+    """8-box scenes whose rotation signature fits / does not fit the ahead-of-time specialised
+    instance (RT_BOX_SIGNATURES): identity matrices fit every single-axis class, a z-rotation or
+    a tilted box in a slot specialised for another axis must fall back to the general instance.
+    Either way the bits are the oracle's (the sparse matrix products are exact)."""
+    case = case_by_name("cornell_v3_8b_wide")
+    sc = cornell_box("v3", aspect=96 / 54)
+    table = {"axis_aligned": [(0, 0, 0)] * 8,
+             "mixed_axes": [(0, 0, 0), (90, 0, 0), (33, 0, 0), (0, 12, 0), (0, 0, 0), (0, -253, 0), (0, 0, 0), (-90, 0, 0)],
+             "tilted": [(0, 0, 0), (90, 0, 0), (90, 0, 0), (0, 90, 0), (0, 90, 0), (10, -253, 5), (0, 0, 30), (90, 0, 0)]}[rots]
+    for o, rot in zip(sc.objects, table):
+        o.transform.rotation[:] = rot
+    o = OracleRenderer(sc, case.cfg)
+    o.sample(3)
+    for opts in ({}, {"specialize": 0}, {"scheduler": 0}):
+        g = Renderer(sc, case.cfg)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        g.sample(3)
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), (rots, opts)
+        g.close()
 
 
 def test_persistent_form_schedulers_agree():

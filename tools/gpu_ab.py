@@ -8,7 +8,7 @@ from oracle_backend import OracleRenderer
 # quick exactness check
 cfg = Config.cornell_v3(128, 128, seed=0, max_raytrace=8); sc = cornell_box("v3")
 SCHED = int(os.environ.get("SCHED", "0"))
-g = Renderer(sc, cfg); g.set_option("scheduler", SCHED); g.sample(8); o = OracleRenderer(sc, cfg); o.sample(8)
+g = Renderer(sc, cfg); g.set_option("scheduler", SCHED); g.set_option("primary_split", int(os.environ.get("PS", "1"))); g.sample(8); o = OracleRenderer(sc, cfg); o.sample(8)
 print("scheduler", SCHED, "bit-exact:", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)), g.counters(), o.counters())
 cfg = Config.cornell_v3(1920, 1080, seed=0, max_raytrace=8)
 sc = cornell_box("v3", aspect=1920 / 1080)
