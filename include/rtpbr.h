@@ -298,6 +298,9 @@ int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking
 /* Device time (HIP events on the context's stream) of the trace kernel launches and of
  * all kernels of the last rtpbr_sample() call, in milliseconds (blocking). */
 int rtpbr_last_sample_ms(rtpbr_ctx* ctx, float* trace_ms, float* total_ms, int* launches);
+/* Device time of the primary_rays launches of the last rtpbr_sample() call (0 launches when
+ * the primary raycasts ran inside the trace kernel: option "primary_split" 0, neural SDF). */
+int rtpbr_last_primary_ms(rtpbr_ctx* ctx, float* primary_ms, int* launches);
 /* Raw stream handle (hipStream_t) so callers can order their own work after ours. */
 int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
 /* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),

@@ -91,6 +91,8 @@ struct rtpbr_ctx {
     // timing
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
+    std::vector<hipEvent_t> evp;   // pairs around the primary_rays launches
+    int evp_used = 0;
     hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
     bool timed = false;
     int n_cu = 256;
@@ -143,6 +145,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->work_counter);
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev_total0);
     (void)hipEventDestroy(c->ev_total1);
     (void)hipStreamDestroy(c->stream);
@@ -402,6 +405,15 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     return RTPBR_OK;
 }
 
+static hipEvent_t next_primary_event(rtpbr_ctx* c) {
+    if (c->evp_used == (int)c->evp.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->evp.push_back(e);
+    }
+    return c->evp[c->evp_used++];
+}
+
 static hipEvent_t next_event(rtpbr_ctx* c) {
     if (c->ev_used == (int)c->ev.size()) {
         hipEvent_t e;
@@ -453,6 +465,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     c->deposits_host = 0;
     c->ev_used = 0;
+    c->evp_used = 0;
     c->timed = true;
     HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
     if (c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY) {
@@ -532,10 +545,15 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             if (chunk < 64) chunk = 64;
             if (chunk > 4096) chunk = 4096;
             P.chunk = (uint32_t)chunk;
-            HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
+            HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
+            if (split) {
+                hipEvent_t pa = next_primary_event(c), pb = next_primary_event(c);
+                HIP_TRY(hipEventRecord(pa, c->stream));
+                launch_primary(P, c->kind, c->n_cu, c->stream);
+                HIP_TRY(hipEventRecord(pb, c->stream));
+            }
             hipEvent_t a = next_event(c), b = next_event(c);
             HIP_TRY(hipEventRecord(a, c->stream));
-            if (split) launch_primary(P, c->kind, c->n_cu, c->stream);
             launch_trace(P, c->kind, grid, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
             launch_accumulate(P, c->stream);
@@ -675,6 +693,22 @@ extern "C" int rtpbr_last_sample_ms(rtpbr_ctx* c, float* trace_ms, float* total_
     if (trace_ms) *trace_ms = tr;
     if (total_ms) *total_ms = tot;
     if (launches) *launches = c->ev_used / 2;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_last_primary_ms(rtpbr_ctx* c, float* primary_ms, int* launches) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (!c->timed) return fail(RTPBR_ESTATE, "no rtpbr_sample() call to time yet");
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float pr = 0.0f;
+    for (int i = 0; i + 1 < c->evp_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->evp[i], c->evp[i + 1]));
+        pr += ms;
+    }
+    if (primary_ms) *primary_ms = pr;
+    if (launches) *launches = c->evp_used / 2;
     return RTPBR_OK;
 }
 

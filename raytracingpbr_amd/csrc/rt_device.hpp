@@ -305,7 +305,7 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
         start = 0;
     } else {
         const ObjM o = tab[0];
-        best = fabs_(signed_distance<KIND>(P, o, p));
+        best = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(0)));
         start = 1;
     }
     if (NOBJ > 0) {

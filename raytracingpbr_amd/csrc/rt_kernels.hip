@@ -267,10 +267,23 @@ __global__ void __launch_bounds__(256) primary_rays(const Params P) {
     const uint32_t n_groups = (P.total_items + 63u) / 64u;
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t n_steps = 0, n_raycasts = 0;
-    // persistent waves, grid-stride over groups of 64 consecutive items (a few thousand resident
-    // blocks; one block per 256 items would be dispatch-bound: 2 M blocks of ~10 us each)
-    for (uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6); g < n_groups; g += n_waves) {
+    // persistent waves (a few thousand resident blocks; one block per 256 items would be
+    // dispatch-bound: 2 M blocks of ~10 us each) that CLAIM runs of 16 consecutive groups of 64
+    // items from a counter: a static stride leaves the slowest wave's tail exposed (average wave
+    // lifetime was 60 % of the kernel)
+    constexpr uint32_t RUN = 16;
+    (void)n_waves;
+    uint32_t g = 0, g_end = 0;
+    for (;;) {
+        if (g == g_end) {
+            uint32_t start = 0;
+            if (lane == 0) start = atomicAdd(P.work_counter + 1, RUN);
+            g = __builtin_amdgcn_readfirstlane(start);
+            if (g >= n_groups) break;
+            g_end = g + RUN < n_groups ? g + RUN : n_groups;
+        }
         const uint32_t item = g * 64u + (uint32_t)lane;
+        g++;
         Lane L;
         L.state = ST_IDLE;
         L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
@@ -437,6 +450,9 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
     int a_bounce = 0;
     uint32_t a_key = 0, a_cnt = 0, a_item = 0;
     uint32_t n_samples = 0;
+    // work counters kept wave-uniform (scalar registers, scalar adds of ballot popcounts) where the
+    // control flow allows it: the per-lane v_add per march step and 3 VGPRs go away
+    uint32_t w_steps = 0, w_raycasts = 0, w_hits = 0;
     WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
     bool b_pending = false;                         // bunny: position evaluated, MLP still to run
@@ -460,6 +476,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
             const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && !wr.drained)));
             if (run_b) {
                 uint32_t st = sstate[lane];
+                w_hits += (uint32_t)__popcll(__ballot(st == SL_HIT));
                 PathRay R;
                 R.o = R.d = R.col = mk(0, 0, 0);
                 R.t_eval = 0.0f;
@@ -479,7 +496,6 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                     if (KIND != KIND_BUNNY) {
                         if (st == SL_HIT) {
                             alive = shade_hit<KIND>(P, lds_obj, R);
-                            L.n_hits++;
                         } else {
                             shade_miss(P, R, L.n_sky);
                         }
@@ -493,7 +509,6 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                     if (__any(st == SL_HIT)) nrm = bunny_normal_wave(P, b_frag, b_lds, lane, hp);
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
-                        L.n_hits++;
                     } else if (st == SL_MISS) {
                         shade_miss(P, R, L.n_sky);
                     }
@@ -565,6 +580,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
             rec[F_KEY] = a_key; rec[F_CNT] = a_cnt; rec[F_ITEM] = a_item;
             const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
             if (r & 2) L.state = ST_IDLE;
+            w_raycasts += (uint32_t)__popcll(__ballot((r & 1) != 0));
             if (r & 1) {
                 L.o = mk(u2f(rec[F_OX]), u2f(rec[F_OY]), u2f(rec[F_OZ]));
                 L.d = mk(u2f(rec[F_DX]), u2f(rec[F_DY]), u2f(rec[F_DZ]));
@@ -610,6 +626,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                         }
                     }
                 } else {
+                    w_steps += (uint32_t)n_march;
                     if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
                 }
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -619,7 +636,9 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
             } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
         }
     }
-    flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, 0);
+    // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
+    flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
+                   lane == 0 ? w_hits : 0u, L.n_sky, n_samples, 0);
 }
 
 // -------------------------------------------------------------------------------------------

@@ -27,8 +27,9 @@ static_assert(sizeof(rtpbr_config) == 160 && sizeof(rtpbr_object) == 116 && size
 enum { ROT_GENERAL = 0, ROT_IDENT = 1, ROT_X = 2, ROT_Y = 3, ROT_Z = 4 };
 // Rotation SIGNATURE of an 8-box scene: 3 bits per object.  The march kernels are additionally
 // instantiated ahead of time for the signatures listed here (the class of every object is then a
-// compile-time constant of the unrolled object loop: no branches).  rtpbr_set_scene picks the first
-// listed signature the scene is compatible with, else the general instance (signature 0).
+// compile-time constant of the unrolled object loop: no branches — a scalar branch per object costs
+// more than the products it saves).  rtpbr_set_scene picks the first listed signature the scene is
+// compatible with, else the general instance (signature 0).
 //   0x4db691: I X X Y Y Y Y X — a room of axis-aligned slabs (90-degree rotations about x or y) with
 //             yawed blocks inside, i.e. the Cornell Box layouts of the reference's examples
 #define RT_BOX_SIGNATURES(X, ...) X(0x4db691u, __VA_ARGS__)

@@ -168,6 +168,12 @@ class Renderer:
         self.api.call("last_sample_ms", self._ctx, C.byref(a), C.byref(b), C.byref(n))
         return a.value, b.value, n.value
 
+    def last_primary_ms(self):
+        """(device ms of the primary_rays launches of the last sample(), number of launches)."""
+        a, n = C.c_float(), C.c_int()
+        self.api.call("last_primary_ms", self._ctx, C.byref(a), C.byref(n))
+        return a.value, n.value
+
     # ------------------------------------------------------------ multi-GPU helpers
     def packed_bytes(self) -> int:
         n = C.c_size_t()

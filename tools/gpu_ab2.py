@@ -13,8 +13,11 @@ for opts in variants:
     for k, v in opts.items(): r.set_option(k, v)
     r.sample(4); r.sync(); rs.append(r)
 best = [1e9] * len(variants)
+parts = [None] * len(variants)
 for rep in range(int(os.environ.get("REPS", "3"))):
     for i, r in enumerate(rs):
-        r.refresh(); r.sample(SPP); tr, tot, n = r.last_sample_ms(); best[i] = min(best[i], tot)
-for opts, b in zip(variants, best):
-    print(json.dumps(opts), f"best total ms={b:.2f} Msamples/s={1920 * 1080 * SPP / b / 1e3:.1f}", flush=True)
+        r.refresh(); r.sample(SPP); tr, tot, n = r.last_sample_ms()
+        if tot < best[i]:
+            best[i], parts[i] = tot, (round(r.last_primary_ms()[0], 2), round(tr, 2), n)
+for opts, b, pt in zip(variants, best, parts):
+    print(json.dumps(opts), f"best total ms={b:.2f} Msamples/s={1920 * 1080 * SPP / b / 1e3:.1f} (primary, trace, launches)={pt}", flush=True)

@@ -3,7 +3,7 @@ import re, sys, subprocess, os, collections
 src = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/raytracingpbr_amd/csrc/rt_kernels.hip"
 kern = sys.argv[2] if len(sys.argv) > 2 else "_ZN2rt11trace_pathsILi1ELi8EEEvNS_6ParamsE"
 os.makedirs("/tmp/probe", exist_ok=True)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-save-temps", "-c", src, "-o", "k.o"],
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-save-temps", "-c", src, "-o", "k.o"],
                cwd="/tmp/probe", stderr=subprocess.DEVNULL)
 s = open("/tmp/probe/" + os.path.basename(src).replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s").read()
 m = re.search(r"^" + re.escape(kern) + r":(.*?)\.Lfunc_end", s, re.S | re.M)
