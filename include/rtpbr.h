@@ -306,8 +306,9 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
 /* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),
  * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
  * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes" (scheduler 1), "waves_per_cu",
- * "primary_split" (1: primary raycasts in their own coherent lock-step kernel with wave-level
- * object culling; pool scheduler, analytic shapes), "specialize" (1: use the instance compiled
+ * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
+ * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
+ * (default), 2 always), "specialize" (1: use the instance compiled
  * for the scene's rotation signature when there is one), "mlp_mfma", "mlp_lanes" (neural SDF),
  * "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */

@@ -31,8 +31,14 @@ RT_D uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Work counters: wave sum -> block sum in LDS -> ONE atomic per counter per block (a persistent
+// grid has thousands of waves; per-wave atomics on the same six addresses serialise for ~0.5 ms).
+// Every wave of the block must call it exactly once (they all do, at the end of the kernel).
 RT_D void flush_counters(const Params& P, uint32_t steps, uint32_t raycasts, uint32_t hits, uint32_t sky,
                          uint32_t samples, uint32_t deposits) {
+    __shared__ unsigned long long blk[6];
+    if (threadIdx.x < 6) blk[threadIdx.x] = 0;
+    __syncthreads();
     steps = wave_sum(steps);
     raycasts = wave_sum(raycasts);
     hits = wave_sum(hits);
@@ -40,12 +46,25 @@ RT_D void flush_counters(const Params& P, uint32_t steps, uint32_t raycasts, uin
     samples = wave_sum(samples);
     deposits = wave_sum(deposits);
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&P.counters->march_steps, (unsigned long long)steps);
-        atomicAdd(&P.counters->raycasts, (unsigned long long)raycasts);
-        atomicAdd(&P.counters->hits, (unsigned long long)hits);
-        atomicAdd(&P.counters->sky_lookups, (unsigned long long)sky);
-        atomicAdd(&P.counters->samples, (unsigned long long)samples);
-        atomicAdd(&P.counters->deposits, (unsigned long long)deposits);
+        if (steps) atomicAdd(&blk[0], (unsigned long long)steps);
+        if (raycasts) atomicAdd(&blk[1], (unsigned long long)raycasts);
+        if (hits) atomicAdd(&blk[2], (unsigned long long)hits);
+        if (sky) atomicAdd(&blk[3], (unsigned long long)sky);
+        if (samples) atomicAdd(&blk[4], (unsigned long long)samples);
+        if (deposits) atomicAdd(&blk[5], (unsigned long long)deposits);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6 && blk[threadIdx.x] != 0) {
+        unsigned long long* dst = &P.counters->samples;   // placeholder, set below
+        switch (threadIdx.x) {
+            case 0: dst = &P.counters->march_steps; break;
+            case 1: dst = &P.counters->raycasts; break;
+            case 2: dst = &P.counters->hits; break;
+            case 3: dst = &P.counters->sky_lookups; break;
+            case 4: dst = &P.counters->samples; break;
+            default: dst = &P.counters->deposits; break;
+        }
+        atomicAdd(dst, blk[threadIdx.x]);
     }
 }
 
@@ -268,11 +287,12 @@ __global__ void __launch_bounds__(256) primary_rays(const Params P) {
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t n_steps = 0, n_raycasts = 0;
     // persistent waves (a few thousand resident blocks; one block per 256 items would be
-    // dispatch-bound: 2 M blocks of ~10 us each) that CLAIM runs of 16 consecutive groups of 64
+    // dispatch-bound: 2 M blocks of ~10 us each) that CLAIM runs of up to 16 consecutive groups of 64
     // items from a counter: a static stride leaves the slowest wave's tail exposed (average wave
     // lifetime was 60 % of the kernel)
-    constexpr uint32_t RUN = 16;
-    (void)n_waves;
+    // run length: 16 groups when there is plenty of work, fewer when that would leave waves idle
+    uint32_t RUN = n_groups / (n_waves * 4u);
+    RUN = RUN < 1u ? 1u : (RUN > 16u ? 16u : RUN);
     uint32_t g = 0, g_end = 0;
     for (;;) {
         if (g == g_end) {

@@ -53,6 +53,15 @@ def test_hip_matches_oracle_bit_exact(case):
         assert np.array_equal(bits(g.diff_pixels), bits(o.diff_pixels))
         assert np.array_equal(bits(g.diff_buffer), bits(o.diff_buffer))
     check_fingerprint(fingerprint(g), case.name)                   # and against the committed golden vectors
+    if case.cfg.kernel_form == 0:
+        # these frames are below the size where the primary raycasts get their own kernel: force it
+        s = Renderer(case.scene, case.cfg)
+        s.set_option("primary_split", 2)
+        case.run(s)
+        cs = s.counters()
+        assert np.array_equal(bits(s.image_buffer), bits(a))
+        assert (cs.raycasts, cs.march_steps, cs.hits, cs.sky_lookups) == (co.raycasts, co.march_steps, co.hits, co.sky_lookups)
+        s.close()
     g.close()
 
 
@@ -136,8 +145,8 @@ def test_schedule_independence():
                  {"scheduler": 1, "shade_lanes": 1, "swap_lanes": 1}, {"scheduler": 1, "shade_lanes": 64, "swap_lanes": 64},
                  {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
-                 {"primary_split": 0}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
-                 {"primary_split": 1, "staging_bytes": 1 << 20, "shade_lanes": 3}):
+                 {"primary_split": 0}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
+                 {"primary_split": 2, "specialize": 0}, {"primary_split": 2, "staging_bytes": 1 << 20, "shade_lanes": 3}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
@@ -169,7 +178,7 @@ def test_rotation_signatures_match_oracle(rots):
         o.transform.rotation[:] = rot
     o = OracleRenderer(sc, case.cfg)
     o.sample(3)
-    for opts in ({}, {"specialize": 0}, {"scheduler": 0}):
+    for opts in ({}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 2, "specialize": 0}, {"scheduler": 0}):
         g = Renderer(sc, case.cfg)
         for k, v in opts.items():
             g.set_option(k, v)
@@ -351,7 +360,10 @@ def test_fuzz_random_scenes_match_oracle(seed):
     counters must equal the oracle's bit for bit."""
     from fuzz import random_case, run
     sc, cfg, env, n = random_case(seed)
-    g = run(Renderer(sc, cfg), env, n, cfg.kernel_form == 1)
+    g = Renderer(sc, cfg)
+    if seed % 2:
+        g.set_option("primary_split", 2)      # small frames: force the separate primary-raycast kernel on half of the cases
+    g = run(g, env, n, cfg.kernel_form == 1)
     o = run(OracleRenderer(sc, cfg), env, n, cfg.kernel_form == 1)
     cg, co = g.counters(), o.counters()
     assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \

@@ -17,6 +17,7 @@ def run(name, sc, cfg, spp, env=None, envexp=1.8, tiles=None, chunk=None, warm=1
     if env is not None: r.set_env(env, envexp, 2.2)
     if any(o.type == SHAPE.BUNNY for o in sc.objects): r.set_shape_data(SHAPE.BUNNY, load_bunny_weights())
     if tiles: r.set_tiles(*tiles)
+    for k, v in json.loads(os.environ.get("OPTS", "{}")).items(): r.set_option(k, v)
     r.sample(warm); r.sync()
     chunk = chunk or spp
     tr_tot, tot_tot, samples, c = 0.0, 0.0, 0, None
