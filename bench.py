@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--scheduler", type=int, default=-1, help="0 = in-register refill, 1 = LDS ray pool (library default)")
     ap.add_argument("--shade-lanes", type=int, default=0)
     ap.add_argument("--swap-lanes", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="rtpbr_set_option knob (A/B runs), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --backend gloo)")
@@ -121,6 +122,9 @@ def main():
         r.set_option("shade_lanes", a.shade_lanes)
     if a.swap_lanes:
         r.set_option("swap_lanes", a.swap_lanes)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        r.set_option(k, int(v))
     dev = torch.device("cuda", local_rank)
     # nccl gathers device tensors (RCCL over xGMI); the gloo functional mode stages through the host
     tg = TileGather(r, rank, world, device=dev if a.backend == "nccl" else None) if world > 1 else None

@@ -71,7 +71,9 @@ struct rtpbr_ctx {
     size_t primary_cap = 0;
     int primary_split = 1;
     int specialize = 1;      // use the RT_BOX_SIGNATURES instance the scene fits
+    int lazy_sqrt = 1;       // all-box scenes: nearest box on squared distances (nearest_boxes_lazy)
     uint32_t scene_sig = 0;
+    ObjM objm[MAX_OBJ];      // march table in its general layout; P.objm is filled per launch (pack_objects)
     unsigned int* work_counter = nullptr;
     Counters* counters = nullptr;
     // tiles
@@ -263,7 +265,7 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
             }
         float rad[3] = {t.rotation[0] * DEG2RAD, t.rotation[1] * DEG2RAD, t.rotation[2] * DEG2RAD};
         rotate(rad, t.matrix);
-        ObjM& m = c->P.objm[i];
+        ObjM& m = c->objm[i];
         m.px = t.position[0]; m.py = t.position[1]; m.pz = t.position[2];
         memcpy(m.m, t.matrix, sizeof m.m);
         m.sx = t.scale[0]; m.sy = t.scale[1]; m.sz = t.scale[2];
@@ -284,7 +286,7 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
         // first listed signature whose every specialised class fits the object's matrix
         // (an identity matrix fits every single-axis class)
         int cls[8];
-        for (int i = 0; i < 8; i++) cls[i] = rotation_class(c->P.objm[i].m);
+        for (int i = 0; i < 8; i++) cls[i] = rotation_class(c->objm[i].m);
         const uint32_t sigs[] = {
 #define RT_SIG_ITEM(sig, ...) sig,
             RT_BOX_SIGNATURES(RT_SIG_ITEM, 0)
@@ -405,6 +407,34 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     return RTPBR_OK;
 }
 
+// Fill the kernel's march table: the general 64-byte blocks, or the signature's packed layout
+// (rt_types.hpp: only the dwords each object's rotation class reads, wide-load friendly).
+static void pack_objects(rtpbr_ctx* c, Params& P) {
+    memset(P.objm, 0, sizeof P.objm);
+    if (P.box_sig == 0) {
+        memcpy(P.objm, c->objm, sizeof(ObjM) * (size_t)c->n_obj);
+        return;
+    }
+    float* f = reinterpret_cast<float*>(P.objm);
+    for (int i = 0; i < c->n_obj; i++) {
+        const ObjM& o = c->objm[i];
+        const int cls = sig_cls(P.box_sig, i);
+        float* d = f + sig_offset(P.box_sig, i);
+        if (cls == ROT_GENERAL) {
+            memcpy(d, &o, sizeof o);
+            continue;
+        }
+        d[0] = o.px, d[1] = o.py, d[2] = o.pz;
+        if (cls == ROT_IDENT) {
+            d[3] = o.sx, d[4] = o.sy, d[5] = o.sz;
+            continue;
+        }
+        const int e[3][4] = {{4, 5, 7, 8}, {0, 2, 6, 8}, {0, 1, 3, 4}};   // X, Y, Z: the four entries that are not 0 / 1
+        for (int k = 0; k < 4; k++) d[3 + k] = o.m[e[cls - ROT_X][k]];
+        d[7] = o.sx, d[8] = o.sy, d[9] = o.sz;
+    }
+}
+
 static hipEvent_t next_primary_event(rtpbr_ctx* c) {
     if (c->evp_used == (int)c->evp.size()) {
         hipEvent_t e;
@@ -457,7 +487,17 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_mfma = c->mlp_mfma;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
-    P.box_sig = c->specialize ? c->scene_sig : 0;
+    // signature instances exist for the complete-path kernels only
+    P.box_sig = (c->specialize && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH) ? c->scene_sig : 0;
+    pack_objects(c, P);
+    {
+        const float rho = c->cfg.box_round;
+        P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
+        P.box_two_rho = rho + rho;
+        P.box_rho2m = (float)((double)rho * (double)rho * (1.0 + 1.0 / 524288.0));
+        if (P.box_rho2m > 0.0f) P.box_rho2m = nextafterf(P.box_rho2m, INFINITY);
+        P.box_4rho2m = nextafterf((float)(4.0 * (double)rho * (double)rho * (1.0 + 1.0 / 524288.0)), INFINITY);
+    }
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
@@ -734,6 +774,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "primary_split")) {
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "primary_split must be 0 (never), 1 (large launches) or 2 (always)");
         c->primary_split = (int)value;
+    } else if (!strcmp(key, "lazy_sqrt")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "lazy_sqrt must be 0 or 1");
+        c->lazy_sqrt = (int)value;
     } else if (!strcmp(key, "specialize")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "specialize must be 0 or 1");
         c->specialize = (int)value;

@@ -293,8 +293,138 @@ RT_D ObjTab obj_table() { return nullptr; }
 
 // rotation class of object i in the kernel's compile-time signature (3 bits per object, 0 = general)
 #define RT_SIG_CLS(i) (int)((SIG >> (3 * (i))) & 7u)
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0, STEP, 2 STEP, ... < N
+template <int N, int STEP, int I = 0, typename F>
+RT_D void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, STEP, I + STEP>(static_cast<F&&>(f));
+    }
+}
+
+// Object I of the march table.  Signature 0: the general 64-byte block.  Otherwise the packed table
+// (rt_types.hpp): wide scalar loads of exactly the dwords the object's rotation class uses.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f8u __attribute__((ext_vector_type(8), aligned(4)));
+typedef float f2u_ __attribute__((ext_vector_type(2), aligned(4)));
+template <uint32_t SIG, int I>
+RT_D ObjM load_obj(ObjTab tab) {
+    if constexpr (SIG == 0) {
+        return tab[I];
+    } else {
+        constexpr int cls = sig_cls(SIG, I);
+        const __attribute__((address_space(4))) float* f = (const __attribute__((address_space(4))) float*)tab + sig_offset(SIG, I);
+        ObjM o = {};
+        if constexpr (cls == ROT_GENERAL) {
+            return *(const __attribute__((address_space(4))) ObjM*)f;
+        } else if constexpr (cls == ROT_IDENT) {
+            const f8u a = *(const __attribute__((address_space(4))) f8u*)f;
+            o.px = a[0], o.py = a[1], o.pz = a[2], o.sx = a[3], o.sy = a[4], o.sz = a[5];
+        } else {
+            // (one s_load_dwordx16 instead of x8 + x2 was measured 2 % slower: more SGPR pressure)
+            const f8u a = *(const __attribute__((address_space(4))) f8u*)f;
+            const f2u_ b = *(const __attribute__((address_space(4))) f2u_*)(f + 8);
+            o.px = a[0], o.py = a[1], o.pz = a[2], o.sx = a[7], o.sy = b[0], o.sz = b[1];
+            if constexpr (cls == ROT_X) o.m[4] = a[3], o.m[5] = a[4], o.m[7] = a[5], o.m[8] = a[6];
+            if constexpr (cls == ROT_Y) o.m[0] = a[3], o.m[2] = a[4], o.m[6] = a[5], o.m[8] = a[6];
+            if constexpr (cls == ROT_Z) o.m[0] = a[3], o.m[1] = a[4], o.m[3] = a[5], o.m[4] = a[6];
+        }
+        return o;
+    }
+}
+#else
+template <uint32_t SIG, int I>
+RT_D ObjM load_obj(ObjTab) { return ObjM{}; }   // host pass only parses the device functions
+#endif
+// ---- all-box scenes: pick the nearest box on SQUARED distances, one square root per step.
+// The correctly rounded square root is a third of a box evaluation and only the winner's distance
+// is used.  With q = |l| - s, s2 = |max(q,0)|^2 and mx = max3(q) the reference distance is
+//     d = | (sqrt(s2) + min(mx,0)) - rho |
+// and, per object, ONE of three cases holds:
+//   outside  (mx > 0, sqrt(s2) > rho):  d = sqrt(s2) - rho          increasing in s2
+//   core     (mx <= 0, s2 = 0):         d = rho - mx                increasing in -mx
+//   shell    (mx > 0, sqrt(s2) <= rho): d = rho - sqrt(s2) <= rho   (an over-relaxed step ended inside the rounding)
+// key = s2 (outside, shell) or (2 rho - mx)^2 (core) orders outside and core objects exactly like d
+// does: d_core < d_out  <=>  rho - mx < sqrt(s2) - rho  <=>  (2 rho - mx)^2 < s2.  The three
+// smallest keys k1 <= k2 <= k3 are tracked (two v_med3 per object).  Rounding can only change an
+// order when two keys agree to ~2^-22, so the lane is SUSPECT when
+//   * k3 <= k1 (1 + 2^-20), or k2 <= k1 (1 + 2^-20) unless k2 == k1 EXACTLY and the lane has no core
+//     object: then both keys are the same s2, hence the same d, and the strict `<` below has kept the
+//     lower index like the reference does (the room's rim corners belong to two slabs: 0.1 % of the
+//     lane-steps are such ties);
+//   * an object is in its shell (k1 < rho^2) and another one is within 2 rho (k2 < 4 rho^2): otherwise
+//     the shell object is the nearest for sure (d <= rho < every other d).
+// If any marching lane of the wave is suspect the function returns false and the caller evaluates the
+// full expression for the wave (~1 % of the wave-steps).  Otherwise (idx, best) are bit-for-bit the
+// reference's: the winner's distance is computed with the same operations, |fl(sqrt_(s2) - rho)| or
+// fl(rho - mx).
+template <int NOBJ, uint32_t SIG>
+RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    const float rho = P.cfg.box_round;
+    const float two_rho = P.box_two_rho;
+    float k1 = 3.0e38f, k2 = 3.0e38f, k3 = 3.0e38f;   // the three smallest keys
+    float pmx = 1.0f;                                  // max3(q) of the object with the smallest key (<= 0: core)
+    bool has_core = false;
+    idx = 0;
+    auto visit = [&](const ObjM& o, int i, int cls) {
+        vec3 l = to_local<KIND_BOXES>(P, o, p, cls);
+        float qx = fabs_(l.x) - o.sx, qy = fabs_(l.y) - o.sy, qz = fabs_(l.z) - o.sz;
+        float mx = fmax_(qx, fmax_(qy, qz));
+        vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
+        float s2 = dot(m, m);
+        float t = two_rho - mx;
+        const bool out = mx > 0.0f;
+        has_core = has_core || !out;
+        float key = out ? s2 : t * t;
+        bool lt = key < k1;
+        k3 = __builtin_amdgcn_fmed3f(key, k2, k3);   // k1 <= k2 <= k3 always: medians insert the new key
+        k2 = __builtin_amdgcn_fmed3f(key, k1, k2);
+        k1 = lt ? key : k1;
+        idx = lt ? i : idx;
+        pmx = lt ? mx : pmx;
+    };
+    static_for<NOBJ, 2>([&](auto I) {   // two objects' constants requested per scalar-load group
+        constexpr int i = decltype(I)::value;
+        const ObjM oa = load_obj<SIG, i>(tab);
+        const ObjM ob = load_obj<SIG, (i + 1 < NOBJ ? i + 1 : i)>(tab);
+        visit(oa, i, RT_SIG_CLS(i));
+        if constexpr (i + 1 < NOBJ) visit(ob, i + 1, RT_SIG_CLS(i + 1));
+    });
+    const float lim = k1 * 1.00000095367431640625f;    // 1 + 2^-20
+    const bool suspect = k3 <= lim || (k2 <= lim && (k2 != k1 || has_core)) || (k1 < P.box_rho2m && k2 < P.box_4rho2m);
+    if (__any(suspect)) return false;
+    const bool core = !(pmx > 0.0f);
+    float d = core ? rho - pmx : fabs_(sqrt_(k1) - rho);
+    if (P.cfg.nearest_init && !(d < P.cfg.max_dis)) {   // src/ form: the search starts from (0, MAX_DIS)
+        d = P.cfg.max_dis;
+        idx = 0;
+    }
+    best = d;
+    return true;
+}
+
+template <int KIND, int NOBJ, uint32_t SIG = 0>
+RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best);
+
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KIND == KIND_BOXES && NOBJ > 0) {
+        if (P.box_lazy && nearest_boxes_lazy<NOBJ, SIG>(P, p, idx, best)) return;
+#ifdef RT_DEBUG_LAZY
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)) == 0) atomicAdd(&P.counters->deposits, 1ull);
+#endif
+    }
+#endif
+    nearest_exact<KIND, NOBJ, SIG>(P, p, idx, best);
+}
+
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best) {
     const int n = NOBJ > 0 ? NOBJ : P.n_obj;
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
@@ -304,30 +434,30 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
         best = P.cfg.max_dis;
         start = 0;
     } else {
-        const ObjM o = tab[0];
+        const ObjM o = load_obj<SIG, 0>(tab);
         best = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(0)));
         start = 1;
     }
-    if (NOBJ > 0) {
-        // two objects per iteration: both 64-byte constant blocks are requested before either is
-        // used, so the scalar-load latency of object i+1 hides behind the arithmetic of object i
-#pragma unroll
-        for (int i = 0; i < NOBJ; i += 2) {
-            const ObjM oa = tab[i];
-            const ObjM ob = tab[i + 1 < NOBJ ? i + 1 : i];
+    if constexpr (NOBJ > 0) {
+        // two objects per iteration: both constant blocks are requested before either is used, so
+        // the scalar-load latency of object i+1 hides behind the arithmetic of object i
+        static_for<NOBJ, 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const ObjM oa = load_obj<SIG, i>(tab);
+            const ObjM ob = load_obj<SIG, (i + 1 < NOBJ ? i + 1 : i)>(tab);
             if (i >= start) {
                 float d = fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i : idx;
             }
-            if (i + 1 < NOBJ) {
+            if constexpr (i + 1 < NOBJ) {
                 float d = fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i + 1 : idx;
             }
-        }
+        });
     } else {
         for (int i = start; i < n; i++) {
             const ObjM o = tab[i];
@@ -361,17 +491,17 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
     best = P.cfg.max_dis;   // the reference starts from object 0 or from MAX_DIS (nearest_init); see below
     idx = 0;
     bool first = !P.cfg.nearest_init;
-#pragma unroll
-    for (int i = 0; i < NOBJ; i++) {
-        if (__all(!active || lb[i] > bound)) continue;            // provably not the nearest for any lane
-        const ObjM o = tab[i];
+    static_for<NOBJ, 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if (__all(!active || lb[i] > bound)) return;              // provably not the nearest for any lane
+        const ObjM o = load_obj<SIG, i>(tab);
         float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i)));
         lb[i] = d - eps;
         bool take = first || d < best;                            // nearest_init = 0: the first visited object initialises
         best = take ? d : best;
         idx = take ? i : idx;
         first = false;
-    }
+    });
 }
 
 // ---------------------------------------------------------------- per-lane path state

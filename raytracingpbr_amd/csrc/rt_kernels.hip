@@ -440,8 +440,13 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
 enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
 static_assert(F_COUNT == POOL_WORDS, "trace record must fill the pool record");
 
+// Waves per SIMD the box instances are compiled for.  The kernel is latency-bound per wave (PMC: a wave
+// issues during 44 % of its cycles, waits on s_waitcnt 27 %, on the issue arbiter 29 %), so more
+// resident waves pay even when the register cap costs a few spills (all of them outside the march
+// loop).  Measured on the headline frame: 4 waves (116 VGPRs) 147.1 ms, 5 (96, 19 spills) 137.6,
+// 6 (80, 32 spills) 132.8, 7 (72, 51 spills) 138.0.
 #ifndef RT_POOL_WAVES
-#define RT_POOL_WAVES 1   // 5 (96 VGPRs, 17 spills) measured +1.5 % but adds 8 GB of scratch traffic per launch: not worth it
+#define RT_POOL_WAVES 6
 #endif
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1)) trace_paths_pool(const Params P) {

@@ -34,6 +34,24 @@ enum { ROT_GENERAL = 0, ROT_IDENT = 1, ROT_X = 2, ROT_Y = 3, ROT_Z = 4 };
 //             yawed blocks inside, i.e. the Cornell Box layouts of the reference's examples
 #define RT_BOX_SIGNATURES(X, ...) X(0x4db691u, __VA_ARGS__)
 
+// A signature instance reads a PACKED object table (host: pack_objects in rt_capi.hip): per object only
+// the dwords its rotation class needs, contiguous and 16-byte granular, so that one or two wide scalar
+// loads fetch them (the general 64-byte block with its unused matrix entries removed by the compiler
+// decays into up to six narrow s_load instructions per object — and every instruction, scalar or
+// vector, costs an issue slot):
+//   general: px py pz m0..m8 sx sy sz type                     16 dwords
+//   X:       px py pz m4 | m5 m7 m8 sx | sy sz - -             12
+//   Y:       px py pz m0 | m2 m6 m8 sx | sy sz - -             12
+//   Z:       px py pz m0 | m1 m3 m4 sx | sy sz - -             12
+//   identity px py pz sx | sy sz - -                            8
+constexpr int sig_cls(uint32_t sig, int i) { return (int)((sig >> (3 * i)) & 7u); }
+constexpr int sig_words(int cls) { return cls == ROT_GENERAL ? 16 : (cls == ROT_IDENT ? 8 : 12); }
+constexpr int sig_offset(uint32_t sig, int i) {
+    int o = 0;
+    for (int j = 0; j < i; j++) o += sig_words(sig_cls(sig, j));
+    return o;
+}
+
 // 16 dwords: what one march step needs from one object
 struct ObjM {
     float px, py, pz;
@@ -93,6 +111,10 @@ struct Params {
     float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
     uint32_t box_sig;       // host side: which RT_BOX_SIGNATURES instance to launch (0 = general)
+    int32_t box_lazy;       // nearest_boxes_lazy enabled (option lazy_sqrt, box_round >= 0)
+    float box_two_rho;      // 2 * box_round
+    float box_rho2m;        // box_round^2 * (1 + 2^-19): a smaller key means an object is in its rounding shell
+    float box_4rho2m;       // (2 box_round)^2 * (1 + 2^-19): a larger key means that object is farther than box_round
     float4* image_buffer;   // T7 (W,H) float4
     float* image_pixels;    // T8 (W,H,3)
     rtpbr_ray* ray_buffer;  // T6

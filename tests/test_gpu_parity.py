@@ -146,7 +146,8 @@ def test_schedule_independence():
                  {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
                  {"primary_split": 0}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
-                 {"primary_split": 2, "specialize": 0}, {"primary_split": 2, "staging_bytes": 1 << 20, "shade_lanes": 3}):
+                 {"primary_split": 2, "specialize": 0}, {"primary_split": 2, "staging_bytes": 1 << 20, "shade_lanes": 3},
+                 {"lazy_sqrt": 0}, {"lazy_sqrt": 0, "specialize": 0, "scheduler": 0}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
@@ -178,7 +179,8 @@ def test_rotation_signatures_match_oracle(rots):
         o.transform.rotation[:] = rot
     o = OracleRenderer(sc, case.cfg)
     o.sample(3)
-    for opts in ({}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 2, "specialize": 0}, {"scheduler": 0}):
+    for opts in ({}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 2, "specialize": 0}, {"scheduler": 0},
+                 {"lazy_sqrt": 0}):
         g = Renderer(sc, case.cfg)
         for k, v in opts.items():
             g.set_option(k, v)
