@@ -440,18 +440,29 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
 enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
 static_assert(F_COUNT == POOL_WORDS, "trace record must fill the pool record");
 
-// Waves per SIMD the box instances are compiled for.  The kernel is latency-bound per wave (PMC: a wave
-// issues during 44 % of its cycles, waits on s_waitcnt 27 %, on the issue arbiter 29 %), so more
-// resident waves pay even when the register cap costs a few spills (all of them outside the march
-// loop).  Measured on the headline frame: 4 waves (116 VGPRs) 147.1 ms, 5 (96, 19 spills) 137.6,
-// 6 (80, 32 spills) 132.8, 7 (72, 51 spills) 138.0.
+// Waves per SIMD the box instances are compiled for.  The kernel is latency-bound per wave (PMC at 4
+// waves: a wave issues during 44 % of its cycles, waits on s_waitcnt 27 %, on the issue arbiter
+// 29 %), so more resident waves pay even when the register cap costs a few spills.  Measured on the
+// headline frame (pool kernel time / HBM-side bytes per launch, of which 18 GB are staging stores
+// and primary records):
+//   4 waves (116 VGPRs, no spill) 147.1 ms / 18 GB      5 waves (96, 14 spills) 137.4 ms / 23 GB
+//   6 waves (80, 27 spills)       132.1 ms / 115 GB     7 waves (72, 51 spills) 138.0 ms
+// 5 is the default: the 6-wave build saves and restores the marching lanes' state around every
+// shading pass through scratch (100 GB per launch) for 4 % more speed.  The marching ray's origin,
+// direction and last distance are parked in LDS during shading (LDS has room for 7 dwords per lane at
+// 6 blocks per CU); build with -DRT_POOL_WAVES=6 to get the faster, scratch-heavy variant.
 #ifndef RT_POOL_WAVES
-#define RT_POOL_WAVES 6
+#define RT_POOL_WAVES 5
+#endif
+#ifndef RT_POOL_WAVES_GENERIC
+#define RT_POOL_WAVES_GENERIC 5   // 114 -> 96 VGPRs, 13 spills: C4 (Tokyo IBL 4K) trace kernel 196 -> 180 ms; 6 waves: 187
 #endif
 template <int KIND, int NOBJ, uint32_t SIG = 0>
-__global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1)) trace_paths_pool(const Params P) {
-    __shared__ ObjFull lds_obj[MAX_OBJ];
+__global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : KIND == KIND_GENERIC ? RT_POOL_WAVES_GENERIC : 1))
+trace_paths_pool(const Params P) {
+    __shared__ ObjFull lds_obj[NOBJ > 0 ? NOBJ : MAX_OBJ];
     __shared__ uint32_t pool_all[4][F_COUNT][64];
+    __shared__ float save_all[(KIND == KIND_BOXES || KIND == KIND_GENERIC) ? 4 : 1][7][64];   // marching state parked during shading
     __shared__ uint32_t sstate_all[4][64];
     __shared__ uint32_t tbl_all[4][64];
     stage_objects(P, lds_obj);
@@ -474,10 +485,9 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
     vec3 a_col = mk(0, 0, 0);
     int a_bounce = 0;
     uint32_t a_key = 0, a_cnt = 0, a_item = 0;
-    uint32_t n_samples = 0;
     // work counters kept wave-uniform (scalar registers, scalar adds of ballot popcounts) where the
     // control flow allows it: the per-lane v_add per march step and 3 VGPRs go away
-    uint32_t w_steps = 0, w_raycasts = 0, w_hits = 0;
+    uint32_t w_steps = 0, w_raycasts = 0, w_hits = 0, w_samples = 0, w_sky = 0;
     WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
     bool b_pending = false;                         // bunny: position evaluated, MLP still to run
@@ -500,6 +510,14 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
             const int n_free = 64 - n_shade - n_ready;
             const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && !wr.drained)));
             if (run_b) {
+                // Shading needs ~60 registers of its own; the marching lanes' ray (origin, direction, relaxation
+                // state) is parked in LDS meanwhile instead of being spilled to scratch by the register cap
+                if constexpr (KIND == KIND_BOXES || KIND == KIND_GENERIC) {
+                    float (*sv)[64] = save_all[wave];
+                    sv[0][lane] = L.o.x, sv[1][lane] = L.o.y, sv[2][lane] = L.o.z;
+                    sv[3][lane] = L.d.x, sv[4][lane] = L.d.y, sv[5][lane] = L.d.z;
+                    sv[6][lane] = L.dist;
+                }
                 uint32_t st = sstate[lane];
                 w_hits += (uint32_t)__popcll(__ballot(st == SL_HIT));
                 PathRay R;
@@ -508,6 +526,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                 R.idx = R.bounce = 0;
                 R.key = R.cnt = R.item = 0;
                 bool alive = false;
+                uint32_t sky1 = 0;   // this slot did an environment lookup
                 if (st == SL_HIT || st == SL_MISS) {
                     R.o = mk(u2f(pool[F_OX][lane]), u2f(pool[F_OY][lane]), u2f(pool[F_OZ][lane]));
                     R.d = mk(u2f(pool[F_DX][lane]), u2f(pool[F_DY][lane]), u2f(pool[F_DZ][lane]));
@@ -522,7 +541,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                         if (st == SL_HIT) {
                             alive = shade_hit<KIND>(P, lds_obj, R);
                         } else {
-                            shade_miss(P, R, L.n_sky);
+                            shade_miss(P, R, sky1);
                         }
                     }
                 }
@@ -535,19 +554,17 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
                     } else if (st == SL_MISS) {
-                        shade_miss(P, R, L.n_sky);
+                        shade_miss(P, R, sky1);
                     }
                 }
-                if (st == SL_HIT || st == SL_MISS) {
-                    if (!alive) {
-                        write_sample(P, R.item, R.col, 1.0f);
-                        n_samples++;
-                    }
-                    st = SL_EMPTY;
-                }
+                w_sky += (uint32_t)__popcll(__ballot(sky1 != 0));
+                if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col, 1.0f);
+                w_samples += (uint32_t)__popcll(__ballot((st == SL_HIT || st == SL_MISS) && !alive));
+                if (st == SL_HIT || st == SL_MISS) st = SL_EMPTY;
                 // refill free slots with fresh pixel-samples
                 bool got = claim_items(P, wr, st == SL_EMPTY && !alive, lane, R.item);
                 uint32_t resumed = 0;   // primary_split: state the primary kernel left this item in
+                bool roulette0 = false;
                 if (got) {
                     int r = start_item(P, R);
                     if (r == 1) {
@@ -560,9 +577,11 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                         } else {
                             alive = true;
                         }
-                    } else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
+                    } else if (r == 0) write_sample(P, R.item, R.col, 1.0f);
                     else write_sample(P, R.item, mk(0, 0, 0), 0.0f);
+                    roulette0 = r == 0;
                 }
+                w_samples += (uint32_t)__popcll(__ballot(roulette0));
                 if (resumed == ST_HIT || resumed == ST_MISS) {
                     // park the finished primary raycast; it is shaded with the next batch
                     pool[F_OX][lane] = f2u(R.o.x); pool[F_OY][lane] = f2u(R.o.y); pool[F_OZ][lane] = f2u(R.o.z);
@@ -589,6 +608,12 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
                 sstate[lane] = st;
                 m_ready = __ballot(st == SL_READY);
                 m_shade = __ballot(st == SL_HIT || st == SL_MISS);   // non-zero only with primary_split
+                if constexpr (KIND == KIND_BOXES || KIND == KIND_GENERIC) {
+                    float (*sv)[64] = save_all[wave];
+                    L.o = mk(sv[0][lane], sv[1][lane], sv[2][lane]);
+                    L.d = mk(sv[3][lane], sv[4][lane], sv[5][lane]);
+                    L.dist = sv[6][lane];
+                }
             }
         }
 
@@ -663,7 +688,7 @@ __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : 1))
     }
     // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
     flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
-                   lane == 0 ? w_hits : 0u, L.n_sky, n_samples, 0);
+                   lane == 0 ? w_hits : 0u, lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);
 }
 
 // -------------------------------------------------------------------------------------------
