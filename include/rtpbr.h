@@ -309,7 +309,9 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
  * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
  * (default), 2 always), "specialize" (1: use the instance compiled
- * for the scene's rotation signature when there is one), "mlp_mfma", "mlp_lanes" (neural SDF),
+ * for the scene's rotation signature when there is one), "lazy_sqrt" (1: all-box scenes pick the
+ * nearest box on squared distances and take one exact square root per march step),
+ * "mlp_mfma", "mlp_lanes" (neural SDF),
  * "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */
 int rtpbr_set_option(rtpbr_ctx* ctx, const char* key, long long value);

@@ -502,6 +502,12 @@ trace_paths_pool(const Params P) {
     auto f2u = [](float x) { return __builtin_bit_cast(uint32_t, x); };
     auto u2f = [](uint32_t x) { return __builtin_bit_cast(float, x); };
 
+#ifdef RT_DEBUG_PHASE
+    unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter();
+#define RT_PHASE(acc) { unsigned long long tn = __builtin_readcyclecounter(); acc += tn - tc; tc = tn; }
+#else
+#define RT_PHASE(acc)
+#endif
     for (;;) {
         // ================================================================ phase B: shade / refill the slots
         {
@@ -617,6 +623,7 @@ trace_paths_pool(const Params P) {
             }
         }
 
+        RT_PHASE(tB)
         // ================================================================ dispatch: swap finished lanes with parked rays
         {
             const bool is_done = L.state == ST_HIT || L.state == ST_MISS;
@@ -641,6 +648,7 @@ trace_paths_pool(const Params P) {
             }
         }
 
+        RT_PHASE(tD)
         // ================================================================ phase A: march
         {
             int n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -685,7 +693,15 @@ trace_paths_pool(const Params P) {
                 // can only be parked, so wait for more of them (bounded by the march lanes running out)
             } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
         }
+        RT_PHASE(tA)
     }
+#ifdef RT_DEBUG_PHASE
+    if (lane == 0) {   // DEBUG: cycles per phase, summed over waves, in the hits / sky / deposits counters
+        atomicAdd(&P.counters->hits, tB >> 10);
+        atomicAdd(&P.counters->sky_lookups, tD >> 10);
+        atomicAdd(&P.counters->deposits, tA >> 10);
+    }
+#endif
     // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
     flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
                    lane == 0 ? w_hits : 0u, lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);
