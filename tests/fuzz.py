@@ -72,3 +72,55 @@ def run(r, env, n, persistent):
         r.sample(n + 1)
     r.post_process()
     return r
+
+
+def random_box8_case(seed):
+    """Eight boxes (the unrolled / signature / squared-distance code paths): overlapping slabs that tie
+    exactly, glass boxes (rays inside a box's core), large rounding radii (rays inside the rounding
+    shell), single-axis and general rotations, both nearest_init conventions."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(24, 72)), int(rng.integers(16, 48))
+    style = seed % 4          # 0: Cornell-like room (fits the listed signature), 1: axis-aligned clutter, 2: single-axis, 3: general
+    objs = []
+    for i in range(8):
+        if style == 0:
+            pos = [(0, 0, -1), (0, 1, 0), (0, -1, 0), (-1, 0, 0), (1, 0, 0), (-0.3, -0.3, -0.2), (0.3, -0.5, 0.2), (0, 0.8, 0)][i]
+            rot = [(0, 0, 0), (90, 0, 0), (90, 0, 0), (0, 90, 0), (0, 90, 0), (0, float(rng.uniform(-180, 180)), 0),
+                   (0, float(rng.uniform(-180, 180)), 0), (90, 0, 0)][i]
+            sc = [(1, 1, 0.2)] * 5 + [(0.25, 0.5, 0.25), (0.25, 0.25, 0.25), (0.2, 0.2, 0.01)]
+            sc = sc[i]
+        else:
+            pos = np.round(rng.uniform(-2, 2, 3) * 2) / 2 if style == 1 else rng.uniform(-2, 2, 3)   # half-integer grid: exact ties
+            if style == 1:
+                rot = tuple(float(90 * rng.integers(-1, 3)) if rng.random() < 0.3 else 0.0 for _ in range(3))
+            elif style == 2:
+                ax = int(rng.integers(0, 3))
+                rot = tuple(float(rng.uniform(-180, 180)) if k == ax else 0.0 for k in range(3))
+            else:
+                rot = tuple(rng.uniform(-180, 180, 3))
+            sc = np.round(rng.uniform(0.2, 1.2, 3) * 4) / 4 if style == 1 else rng.uniform(0.1, 1.2, 3)
+        kind = int(rng.integers(0, 4))
+        if i == 7 or kind == 3:
+            m = Material((1, 1, 1), rng.uniform(5, 40, 3), 1.0, 0.0, 0.0, 1.0)                                    # light
+        elif kind == 0:
+            m = Material(rng.uniform(0.2, 1, 3), (1, 1, 1), 1.0, 0.0, 0.0, 1.5)                                   # diffuse
+        elif kind == 1:
+            m = Material(rng.uniform(0.5, 1, 3), (1, 1, 1), float(rng.uniform(0, 0.3)), 1.0, 0.0, 1.5)            # metal
+        else:
+            m = Material(rng.uniform(0.8, 1, 3), (1, 1, 1), float(rng.uniform(0, 0.1)), 0.0, 1.0, float(rng.uniform(1.1, 1.8)))  # glass
+        objs.append(SDFObject(SHAPE.BOX, Transform(pos, rot, sc), m))
+    scale10 = style == 0                                       # the examples' x10 scene scale
+    cam = Camera((float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)), 35.0 if style == 0 else 6.0), (0, 0, 0), (0, 1, 0),
+                 float(rng.uniform(30, 50)), W / H, float(rng.uniform(0, 0.05)), 4.0)
+    if seed % 5 == 4:
+        cfg = Config.src(W, H, seed, steps_per_launch=int(rng.integers(1, 4)))
+        cfg.sky_kind = 0                                       # gradient sky: no environment map needed
+    else:
+        cfg = Config.cornell_v3(W, H, seed, int(rng.integers(2, 10)))
+        cfg.march_kind = int(rng.integers(0, 2))
+        cfg.omega0 = float(rng.choice([1.0, 1.6, 1.9]))       # 1.9: many over-relaxed steps end inside boxes
+        cfg.min_dis = float(rng.choice([0.05, 0.005]))
+        cfg.hit_eps = float(rng.choice([cfg.hit_eps, 1e-3]))
+    cfg.nearest_init = int(rng.integers(0, 2))
+    cfg.box_round = float(rng.choice([0.0, 0.01, 0.1, 0.3]))
+    return Scene(objs, scale10, cam, f"box8_{seed}"), cfg, None, int(rng.integers(2, 6))

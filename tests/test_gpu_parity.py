@@ -377,6 +377,29 @@ def test_fuzz_random_scenes_match_oracle(seed):
     g.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_eight_box_scenes_match_oracle(seed):
+    """8-box scenes drive the unrolled kernels: signature instances with the packed object table,
+    the squared-distance nearest-box search (exact ties between overlapping slabs, rays inside a
+    box or inside its rounding shell, both start conventions) and the culled primary kernel."""
+    from fuzz import random_box8_case, run
+    sc, cfg, env, n = random_box8_case(seed)
+    o = run(OracleRenderer(sc, cfg), env, n, cfg.kernel_form == 1)
+    co = o.counters()
+    for opts in ({}, {"primary_split": 2}, {"lazy_sqrt": 0, "specialize": 0}):
+        g = Renderer(sc, cfg)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        g = run(g, env, n, cfg.kernel_form == 1)
+        cg = g.counters()
+        assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
+               (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits), opts
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), opts
+        if cfg.kernel_form == 1:
+            assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), opts
+        g.close()
+
+
 def test_edge_cases_match_oracle():
     """Degenerate sizes: 1x1 frame, 32 objects (RTPBR_MAX_OBJECTS), sample(0), a tile larger than
     the frame, more ranks than tiles (a rank that owns nothing), odd frame sizes vs tile edges."""
