@@ -248,6 +248,55 @@ static int rotation_class(const float* m) {
     return ROT_GENERAL;
 }
 
+// First listed signature (RT_BOX_SIGNATURES) whose every specialised class fits the object's matrix;
+// an identity matrix fits every single-axis class.  0 = the general instance.
+static uint32_t choose_signature(const ObjM* objm) {
+    int cls[8];
+    for (int i = 0; i < 8; i++) cls[i] = rotation_class(objm[i].m);
+    const uint32_t sigs[] = {
+#define RT_SIG_ITEM(sig, ...) sig,
+        RT_BOX_SIGNATURES(RT_SIG_ITEM, 0)
+#undef RT_SIG_ITEM
+    };
+    for (uint32_t sig : sigs) {
+        bool ok = true;
+        for (int i = 0; i < 8 && ok; i++) {
+            const int want = sig_cls(sig, i);
+            ok = want == ROT_GENERAL || want == cls[i] || cls[i] == ROT_IDENT;
+        }
+        if (ok) return sig;
+    }
+    return 0;
+}
+
+// Fill a march table: the general 64-byte blocks, or the signature's packed layout (rt_types.hpp:
+// only the dwords each object's rotation class reads, wide-load friendly).
+static void pack_table(const ObjM* src, int n, uint32_t sig, ObjM* dst_table) {
+    memset(dst_table, 0, sizeof(ObjM) * MAX_OBJ);
+    if (sig == 0) {
+        memcpy(dst_table, src, sizeof(ObjM) * (size_t)n);
+        return;
+    }
+    float* f = reinterpret_cast<float*>(dst_table);
+    for (int i = 0; i < n; i++) {
+        const ObjM& o = src[i];
+        const int cls = sig_cls(sig, i);
+        float* d = f + sig_offset(sig, i);
+        if (cls == ROT_GENERAL) {
+            memcpy(d, &o, sizeof o);
+            continue;
+        }
+        d[0] = o.px, d[1] = o.py, d[2] = o.pz;
+        if (cls == ROT_IDENT) {
+            d[3] = o.sx, d[4] = o.sy, d[5] = o.sz;
+            continue;
+        }
+        const int e[3][4] = {{4, 5, 7, 8}, {0, 2, 6, 8}, {0, 1, 3, 4}};   // X, Y, Z: the four entries that are not 0 / 1
+        for (int k = 0; k < 4; k++) d[3 + k] = o.m[e[cls - ROT_X][k]];
+        d[7] = o.sx, d[8] = o.sy, d[9] = o.sz;
+    }
+}
+
 extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, int scale10) {
     if (!c || !objs) return fail(RTPBR_EINVAL, "null argument");
     if (n <= 0 || n > MAX_OBJ) return fail(RTPBR_EINVAL, "object count must be 1..32");
@@ -281,35 +330,45 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
         else any_bunny = true;
         if (m.type < RTPBR_SHAPE_NONE || m.type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
     }
-    c->scene_sig = 0;
-    if (all_box && n == 8) {
-        // first listed signature whose every specialised class fits the object's matrix
-        // (an identity matrix fits every single-axis class)
-        int cls[8];
-        for (int i = 0; i < 8; i++) cls[i] = rotation_class(c->objm[i].m);
-        const uint32_t sigs[] = {
-#define RT_SIG_ITEM(sig, ...) sig,
-            RT_BOX_SIGNATURES(RT_SIG_ITEM, 0)
-#undef RT_SIG_ITEM
-        };
-        for (uint32_t sig : sigs) {
-            bool ok = true;
-            for (int i = 0; i < 8 && ok; i++) {
-                const int want = (int)((sig >> (3 * i)) & 7u);
-                ok = want == ROT_GENERAL || want == cls[i] || (cls[i] == ROT_IDENT && want != ROT_IDENT);
-            }
-            if (ok) {
-                c->scene_sig = sig;
-                break;
-            }
-        }
-    }
+    c->scene_sig = (all_box && n == 8) ? choose_signature(c->objm) : 0;
     c->n_obj = n;
     c->P.n_obj = n;
     c->kind = all_box ? KIND_BOXES : (all_bunny && n == 1) ? KIND_BUNNY : any_bunny ? KIND_MIXED : KIND_GENERIC;
     HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
     c->have_scene = true;
+    return RTPBR_OK;
+}
+
+// Test hook, HOST ONLY (no device needed): the signature an 8-box scene would be rendered with and
+// its packed march table (128 floats), for tests/test_host_logic.py.
+extern "C" int rtpbr_test_signature(const rtpbr_object* objs, int n, int scale10, uint32_t* sig, float* table) {
+    if (!objs || !sig || n != 8) return RTPBR_EINVAL;
+    ObjM objm[MAX_OBJ];
+    memset(objm, 0, sizeof objm);
+    bool all_box = true;
+    for (int i = 0; i < n; i++) {
+        rtpbr_transform t = objs[i].transform;
+        if (scale10)
+            for (int k = 0; k < 3; k++) {
+                t.position[k] *= 10.0f;
+                t.scale[k] *= 10.0f;
+            }
+        float rad[3] = {t.rotation[0] * DEG2RAD, t.rotation[1] * DEG2RAD, t.rotation[2] * DEG2RAD};
+        rotate(rad, t.matrix);
+        ObjM& m = objm[i];
+        m.px = t.position[0]; m.py = t.position[1]; m.pz = t.position[2];
+        memcpy(m.m, t.matrix, sizeof m.m);
+        m.sx = t.scale[0]; m.sy = t.scale[1]; m.sz = t.scale[2];
+        m.type = objs[i].type;
+        if (m.type != RTPBR_SHAPE_BOX) all_box = false;
+    }
+    *sig = all_box ? choose_signature(objm) : 0;
+    if (table) {
+        ObjM packed[MAX_OBJ];
+        pack_table(objm, n, *sig, packed);
+        memcpy(table, packed, 128 * sizeof(float));
+    }
     return RTPBR_OK;
 }
 
@@ -407,33 +466,7 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     return RTPBR_OK;
 }
 
-// Fill the kernel's march table: the general 64-byte blocks, or the signature's packed layout
-// (rt_types.hpp: only the dwords each object's rotation class reads, wide-load friendly).
-static void pack_objects(rtpbr_ctx* c, Params& P) {
-    memset(P.objm, 0, sizeof P.objm);
-    if (P.box_sig == 0) {
-        memcpy(P.objm, c->objm, sizeof(ObjM) * (size_t)c->n_obj);
-        return;
-    }
-    float* f = reinterpret_cast<float*>(P.objm);
-    for (int i = 0; i < c->n_obj; i++) {
-        const ObjM& o = c->objm[i];
-        const int cls = sig_cls(P.box_sig, i);
-        float* d = f + sig_offset(P.box_sig, i);
-        if (cls == ROT_GENERAL) {
-            memcpy(d, &o, sizeof o);
-            continue;
-        }
-        d[0] = o.px, d[1] = o.py, d[2] = o.pz;
-        if (cls == ROT_IDENT) {
-            d[3] = o.sx, d[4] = o.sy, d[5] = o.sz;
-            continue;
-        }
-        const int e[3][4] = {{4, 5, 7, 8}, {0, 2, 6, 8}, {0, 1, 3, 4}};   // X, Y, Z: the four entries that are not 0 / 1
-        for (int k = 0; k < 4; k++) d[3 + k] = o.m[e[cls - ROT_X][k]];
-        d[7] = o.sx, d[8] = o.sy, d[9] = o.sz;
-    }
-}
+static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj, P.box_sig, P.objm); }
 
 static hipEvent_t next_primary_event(rtpbr_ctx* c) {
     if (c->evp_used == (int)c->evp.size()) {

@@ -108,3 +108,71 @@ def test_synthetic_env_is_deterministic():
     assert hashlib.sha1(e.tobytes()).hexdigest() == "2606c581d11bcf02e1cd7047fa6ba08fa0f64640"
     p = preprocess(e, 1.4, 2.2)
     assert p.dtype == np.float32 and p.max() == pytest.approx(1.4 ** 2.2, rel=1e-5)   # 2.10
+
+
+def _signature(scene):
+    """Host-only hook of the HIP library (no device call): signature + packed march table."""
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    f = lib.rtpbr_test_signature
+    f.restype = C.c_int
+    objs = (rt.SDFObject * 8)(*scene.objects)
+    sig = C.c_uint32(123)
+    table = (C.c_float * 128)()
+    assert f(objs, 8, int(scene.scale10), C.byref(sig), table) == 0
+    return sig.value, np.array(table, dtype=np.float32)
+
+
+def test_rotation_signature_and_packed_table():
+    """rtpbr_set_scene's host logic for 8-box scenes: the Cornell layouts (and anything made of
+    identity / matching single-axis rotations) get the listed signature 0x4db691 and a packed table
+    that holds exactly the dwords each class reads; a rotation about another axis, a tilted box or a
+    non-box shape fall back to the general instance (signature 0, plain 64-byte blocks)."""
+    CORNELL = 0x4DB691          # classes I X X Y Y Y Y X, 3 bits per object (rt_types.hpp)
+    for variant in ("v1", "v2", "v3", "shortest"):
+        assert _signature(rt.cornell_box(variant))[0] == CORNELL
+    sc = rt.cornell_box("v3")
+    for o in sc.objects:
+        o.transform.rotation[:] = (0, 0, 0)
+    assert _signature(sc)[0] == CORNELL                       # an identity fits every single-axis class
+    sc = rt.cornell_box("v3")
+    sc.objects[3].transform.rotation[:] = (0, 0, 30)          # z-rotation in a slot specialised for y
+    assert _signature(sc)[0] == 0
+    sc = rt.cornell_box("v3")
+    sc.objects[5].transform.rotation[:] = (10, -253, 5)       # tilted block
+    assert _signature(sc)[0] == 0
+    sc = rt.cornell_box("v3")
+    sc.objects[6].type = int(rt.SHAPE.SPHERE)
+    assert _signature(sc)[0] == 0
+
+    # packed layout: identity 8 dwords [pos, size, -, -]; X / Y 12 dwords [pos, 4 matrix entries, size, -, -]
+    sc = rt.cornell_box("v3")
+    sig, tab = _signature(sc)
+    objs = sc.objects
+    s10 = 10.0 if sc.scale10 else 1.0
+    off = 0
+    cls = [(sig >> (3 * i)) & 7 for i in range(8)]
+    assert cls == [1, 2, 2, 3, 3, 3, 3, 2]
+    for i, o in enumerate(objs):
+        pos = np.array(list(o.transform.position), np.float32) * np.float32(s10)
+        size = np.array(list(o.transform.scale), np.float32) * np.float32(s10)
+        assert np.array_equal(tab[off:off + 3], pos)
+        if cls[i] == 1:
+            assert np.array_equal(tab[off + 3:off + 6], size)
+            off += 8
+        else:
+            assert np.array_equal(tab[off + 7:off + 10], size)
+            m = tab[off + 3:off + 7]
+            ang = np.deg2rad(o.transform.rotation[0] if cls[i] == 2 else o.transform.rotation[1])
+            # X: m4 m5 m7 m8 = c s -s c;  Y: m0 m2 m6 m8 = c -s s c  (row-major world->local)
+            want = [np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)] if cls[i] == 2 else \
+                   [np.cos(ang), -np.sin(ang), np.sin(ang), np.cos(ang)]
+            assert np.allclose(m, want, atol=1e-6), (i, m, want)
+            off += 12
+    assert off == 8 + 7 * 12 and np.all(tab[off:] == 0)
+    # signature 0: plain blocks (position, 9 matrix entries, size, type)
+    sc.objects[5].transform.rotation[:] = (10, -253, 5)
+    sig, tab = _signature(sc)
+    assert sig == 0
+    blk = tab.reshape(8, 16)
+    assert np.array_equal(blk[0, :3], np.array([0, 0, -10], np.float32)) and np.array_equal(blk[0, 3:12], np.eye(3, dtype=np.float32).ravel())
+    assert blk[:, 15].view(np.int32).tolist() == [int(rt.SHAPE.BOX)] * 8
