@@ -36,11 +36,23 @@ def oracle_api():
     return _api
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU
+    box shows 256 logical CPUs to a container limited to 16; 256 OpenMP threads on 16 cores crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
 class OracleRenderer(Renderer):
     def __init__(self, scene, config, camera=None, threads=0):
         super().__init__(scene, config, camera, device=0, api=oracle_api())
-        if threads:
-            self.api.lib.rto_set_threads(self._ctx, threads)
+        self.api.lib.rto_set_threads(self._ctx, threads or min(usable_cores(), 32))
 
     def set_sample_base(self, base):
         self.api.lib.rto_set_sample_base(self._ctx, base)
