@@ -128,6 +128,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     # nccl gathers device tensors (RCCL over xGMI); the gloo functional mode stages through the host
     tg = TileGather(r, rank, world, device=dev if a.backend == "nccl" else None) if world > 1 else None
+    r.set_option("reserve_spp", SPP)     # device buffers are allocated before the timed region, whatever --warmup is
 
     def step():
         r.refresh()

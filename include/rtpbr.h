@@ -312,7 +312,8 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * for the scene's rotation signature when there is one), "lazy_sqrt" (1: all-box scenes pick the
  * nearest box on squared distances and take one exact square root per march step),
  * "mlp_mfma", "mlp_lanes" (neural SDF),
- * "sample_base" (absolute index of the next sample: checkpoint/resume).
+ * "reserve_spp" (allocate the staging of a call of that many samples per pixel now instead of on
+ * first use), "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */
 int rtpbr_set_option(rtpbr_ctx* ctx, const char* key, long long value);
 

@@ -468,6 +468,31 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
 
 static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj, P.box_sig, P.objm); }
 
+// Staging (one float4 per item) and, for the primary split, the primary records (one float2 per item).
+// Grown on demand; hipMalloc of several GB takes 50..700 ms, so callers that time whole frames can
+// reserve up front (option "reserve_spp").
+static int ensure_staging(rtpbr_ctx* c, size_t items, bool split) {
+    const size_t need = items * sizeof(float4);
+    if (need > c->stage_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_cap = 0;
+        HIP_TRY(hipMalloc(&c->stage, need));
+        c->stage_cap = need;
+    }
+    const size_t pneed = items * sizeof(float2);
+    if (split && pneed > c->primary_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->primary);
+        c->primary = nullptr;
+        c->primary_cap = 0;
+        HIP_TRY(hipMalloc(&c->primary, pneed));
+        c->primary_cap = pneed;
+    }
+    return RTPBR_OK;
+}
+
 static hipEvent_t next_primary_event(rtpbr_ctx* c) {
     if (c->evp_used == (int)c->evp.size()) {
         hipEvent_t e;
@@ -588,26 +613,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             int K = (int)(left < kmax ? left : kmax);
             // the extra launch has a fixed cost of ~0.3 ms: below ~8 M items the fused kernel is faster
             const bool split = split_ok && (c->primary_split == 2 || (long long)P.np * K >= (1LL << 23));
-            size_t need = (size_t)P.np * (size_t)K * sizeof(float4);
-            if (need > c->stage_cap) {
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                (void)hipFree(c->stage);
-                c->stage = nullptr;
-                c->stage_cap = 0;
-                HIP_TRY(hipMalloc(&c->stage, need));
-                c->stage_cap = need;
-            }
-            if (split) {
-                size_t pneed = (size_t)P.np * (size_t)K * sizeof(float2);
-                if (pneed > c->primary_cap) {
-                    HIP_TRY(hipStreamSynchronize(c->stream));
-                    (void)hipFree(c->primary);
-                    c->primary = nullptr;
-                    c->primary_cap = 0;
-                    HIP_TRY(hipMalloc(&c->primary, pneed));
-                    c->primary_cap = pneed;
-                }
-            }
+            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split)) return r;
             P.primary = c->primary;
             P.primary_split = split ? 1 : 0;
             P.stage = c->stage;
@@ -828,6 +834,19 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(RTPBR_EINVAL, "waves_per_cu must be 0..32");
         c->waves_per_cu = (int)value;
+    } else if (!strcmp(key, "reserve_spp")) {
+        // allocate the staging of a `value`-spp rtpbr_sample() call now (complete-path form)
+        if (!c->have_cfg || c->P.np <= 0) return fail(RTPBR_ESTATE, "set_config (and set_tiles) first");
+        if (value < 1) return fail(RTPBR_EINVAL, "reserve_spp must be >= 1");
+        if (int r = set_dev(c)) return r;
+        const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
+        long long per_spp = (long long)c->P.np * (long long)(sizeof(float4) + (split_ok ? sizeof(float2) : 0));
+        long long kmax = c->staging_bytes / per_spp;
+        long long k32 = 0xFFFFFFFFLL / (long long)c->P.np - 1;
+        if (kmax > k32) kmax = k32;
+        if (kmax < 1) kmax = 1;
+        const long long K = value < kmax ? value : kmax;
+        if (int r = ensure_staging(c, (size_t)c->P.np * (size_t)K, split_ok)) return r;
     } else if (!strcmp(key, "sample_base")) {
         c->sample_base = (uint32_t)value;
     } else {
