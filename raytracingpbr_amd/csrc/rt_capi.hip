@@ -549,6 +549,21 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.box_sig = (c->specialize && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH) ? c->scene_sig : 0;
     pack_objects(c, P);
     {
+        // nearest_culled needs |sdf| to be 1-Lipschitz: true for every analytic shape except a cone whose
+        // slope vector (scale.x, scale.z) is longer than 1; the rounding allowance scales with the scene
+        float ext = 16.0f;
+        bool ok = c->n_obj <= 8 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
+        for (int i = 0; i < c->n_obj; i++) {
+            const ObjM& o = c->objm[i];
+            const float e = fabsf(o.px) + fabsf(o.py) + fabsf(o.pz) + fabsf(o.sx) + fabsf(o.sy) + fabsf(o.sz);
+            if (!(e <= 1e12f)) ok = false;
+            if (e > ext) ext = e;
+            if (o.type == RTPBR_SHAPE_CONE && !(o.sx * o.sx + o.sz * o.sz <= 1.0f)) ok = false;
+        }
+        P.cull_ok = ok ? 1 : 0;
+        P.cull_extent = 4.0f * ext;
+    }
+    {
         const float rho = c->cfg.box_round;
         P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
         P.box_two_rho = rho + rho;

@@ -478,21 +478,28 @@ RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best) {
 // Object i is skipped when lb_i > ub for EVERY lane (wave-uniform branch): then |sdf_i| > min strictly,
 // so it is neither the nearest nor a tie and (index, distance) are exactly what the full loop gives.
 // Objects are still visited in index order with the strict `<` of the reference, so ties resolve
-// identically.  eps covers the rounding of the computed distances (|error| <~ 10 ulp(|pos|); we
-// allow 2^-19 (t + 64) on each side).  lb[] and ub are maintained by the caller across steps.
+// identically.  eps covers the rounding of the computed distances (|error| <~ 10 ulp of the largest
+// intermediate, |pos - centre| + size); we allow 2^-19 (t + extent) on each side, extent = max(64,
+// 4 max_i(|centre_i| + |size_i|)) from the host.  lb[] and ub are maintained by the caller across
+// steps.  Works for every shape whose SDF is 1-Lipschitz (sphere, box, cylinder, plane, none; the host
+// checks the cone's slope vector and excludes the neural SDF).  With signature 0 the table may hold
+// fewer than NOBJ objects (runtime count, compile-time unrolling).
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub, float (&lb)[NOBJ > 0 ? NOBJ : 1],
                          int& idx, float& best) {
     static_assert(NOBJ > 0, "culling needs a compile-time object count");
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
-    const float eps = 1.9073486328125e-06f * (fabs_(t) + 64.0f);
+    const float eps = 1.9073486328125e-06f * (fabs_(t) + P.cull_extent);
     const float bound = ub + eps;
     best = P.cfg.max_dis;   // the reference starts from object 0 or from MAX_DIS (nearest_init); see below
     idx = 0;
     bool first = !P.cfg.nearest_init;
     static_for<NOBJ, 1>([&](auto I) {
         constexpr int i = decltype(I)::value;
+        if constexpr (SIG == 0) {
+            if (i >= P.n_obj) return;
+        }
         if (__all(!active || lb[i] > bound)) return;              // provably not the nearest for any lane
         const ObjM o = load_obj<SIG, i>(tab);
         float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i)));

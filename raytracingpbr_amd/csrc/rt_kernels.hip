@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) primary_rays(const Params P) {
                 march_init(P, L);
             }
         }
-        if constexpr (NOBJ > 0 && KIND == KIND_BOXES) {
+        if constexpr (NOBJ > 0 && KIND != KIND_BUNNY && KIND != KIND_MIXED) {
             float lb[NOBJ > 0 ? NOBJ : 1];
 #pragma unroll
             for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] = -1.0f;   // nothing known yet: everything is evaluated
@@ -1209,6 +1209,15 @@ void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st) {
     long long grid = (long long)n_cu * 8;            // 32 waves per CU: the kernel needs only ~40 VGPRs
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
+    // scenes of up to 8 one-Lipschitz shapes use the culling instance (8-way unrolled, runtime object count)
+    if (P.cull_ok && P.box_sig == 0 && kind == KIND_GENERIC) {
+        hipLaunchKernelGGL((primary_rays<KIND_GENERIC, 8>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        return;
+    }
+    if (P.cull_ok && P.box_sig == 0 && kind == KIND_BOXES && P.n_obj < 8) {
+        hipLaunchKernelGGL((primary_rays<KIND_BOXES, 8>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        return;
+    }
     RT_DISPATCH_KIND(primary_rays, hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), 0, st, P));
 }
 int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler) {

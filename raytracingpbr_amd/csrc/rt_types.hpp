@@ -111,6 +111,8 @@ struct Params {
     float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
     uint32_t box_sig;       // host side: which RT_BOX_SIGNATURES instance to launch (0 = general)
+    int32_t cull_ok;        // host side: every shape is 1-Lipschitz and n_obj <= 8: primary_rays may cull (nearest_culled)
+    float cull_extent;      // nearest_culled: scale of the rounding allowance
     int32_t box_lazy;       // nearest_boxes_lazy enabled (option lazy_sqrt, box_round >= 0)
     float box_two_rho;      // 2 * box_round
     float box_rho2m;        // box_round^2 * (1 + 2^-19): a smaller key means an object is in its rounding shell
