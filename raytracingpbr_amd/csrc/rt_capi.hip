@@ -300,6 +300,8 @@ static void pack_table(const ObjM* src, int n, uint32_t sig, ObjM* dst_table) {
 extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, int scale10) {
     if (!c || !objs) return fail(RTPBR_EINVAL, "null argument");
     if (n <= 0 || n > MAX_OBJ) return fail(RTPBR_EINVAL, "object count must be 1..32");
+    for (int i = 0; i < n; i++)   // validate before touching the context
+        if (objs[i].type < RTPBR_SHAPE_NONE || objs[i].type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
     if (int r = set_dev(c)) return r;
     ObjFull full[MAX_OBJ];
     memset(full, 0, sizeof full);
@@ -328,7 +330,6 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
         if (m.type != RTPBR_SHAPE_BOX) all_box = false;
         if (m.type != RTPBR_SHAPE_BUNNY) all_bunny = false;
         else any_bunny = true;
-        if (m.type < RTPBR_SHAPE_NONE || m.type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
     }
     c->scene_sig = (all_box && n == 8) ? choose_signature(c->objm) : 0;
     c->n_obj = n;

@@ -284,6 +284,22 @@ def test_error_channel():
         r.set_option("no_such_option", 1)
     with pytest.raises(ValueError):
         r.image_buffer = np.zeros((3, 3, 4), np.float32)
+    # a rejected scene leaves the context as it was
+    good = cornell_box("v3")
+    g = Renderer(good, Config.cornell_v3(32, 32, 1, 3))
+    g.sample(2)
+    want = bits(g.image_buffer).copy()
+    bad_scene = cornell_box("v3")
+    bad_scene.objects[5].type = 77
+    with pytest.raises(RtpbrError):
+        g.set_scene(bad_scene)
+    g.refresh()
+    g.sample(2)
+    assert np.array_equal(bits(g.image_buffer), want)
+    g.set_option("reserve_spp", 64)                      # allocation only: results unchanged
+    g.refresh()
+    g.sample(2)
+    assert np.array_equal(bits(g.image_buffer), want)
 
 
 def test_full_size_cornell_1080p():
