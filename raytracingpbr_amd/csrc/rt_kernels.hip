@@ -571,11 +571,14 @@ trace_paths_pool(const Params P) {
                 bool got = claim_items(P, wr, st == SL_EMPTY && !alive, lane, R.item);
                 uint32_t resumed = 0;   // primary_split: state the primary kernel left this item in
                 bool roulette0 = false;
+                // the primary record is requested BEFORE the camera ray is regenerated: the ~150 instructions of
+                // start_item cover part of the global-load latency
+                float2 rec = make_float2(0.0f, 0.0f);
+                if (got && P.primary_split) rec = P.primary[R.item];
                 if (got) {
                     int r = start_item(P, R);
                     if (r == 1) {
                         if (P.primary_split) {
-                            const float2 rec = P.primary[R.item];
                             const uint32_t code = __builtin_bit_cast(uint32_t, rec.y);
                             R.t_eval = rec.x;
                             R.idx = (int)(code & 0xffu);
