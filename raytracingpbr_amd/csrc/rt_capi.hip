@@ -546,6 +546,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_mfma = c->mlp_mfma;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
+    // the pool kernel's parked records hold the bounce number in 11 bits
+    if (c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && c->cfg.max_raytrace > 2047) P.scheduler = 0;
     // signature instances exist for the complete-path kernels only
     P.box_sig = (c->specialize && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH) ? c->scene_sig : 0;
     pack_objects(c, P);

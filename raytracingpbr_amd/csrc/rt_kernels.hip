@@ -375,13 +375,15 @@ struct PoolView {
 RT_D int wave_rank(unsigned long long m) {   // number of set bits below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
-RT_D void pool_load(const PoolView& V, uint32_t slot, uint32_t (&rec)[POOL_WORDS]) {
+template <int W>
+RT_D void pool_load(const PoolView& V, uint32_t slot, uint32_t (&rec)[W]) {
 #pragma unroll
-    for (int w = 0; w < POOL_WORDS; w++) rec[w] = V.pool[w][slot];
+    for (int w = 0; w < W; w++) rec[w] = V.pool[w][slot];
 }
-RT_D void pool_store(const PoolView& V, uint32_t slot, const uint32_t (&rec)[POOL_WORDS]) {
+template <int W>
+RT_D void pool_store(const PoolView& V, uint32_t slot, const uint32_t (&rec)[W]) {
 #pragma unroll
-    for (int w = 0; w < POOL_WORDS; w++) V.pool[w][slot] = rec[w];
+    for (int w = 0; w < W; w++) V.pool[w][slot] = rec[w];
 }
 
 // Swap finished lanes with parked READY records (wave-uniform control flow; all lanes call it).
@@ -392,8 +394,9 @@ RT_D void pool_store(const PoolView& V, uint32_t slot, const uint32_t (&rec)[POO
 // requester gets the j-th listed slot: both sides are ranked with ballot + mbcnt prefix counts and
 // matched through the 64-entry table.  Returns bit 0 = rec[] now holds a taken READY record,
 // bit 1 = this lane's record was parked.  m_ready / m_shade are refreshed from the slot states.
+template <int W>
 RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint32_t done_state,
-                   uint32_t (&rec)[POOL_WORDS], unsigned long long& m_ready, unsigned long long& m_shade) {
+                   uint32_t (&rec)[W], unsigned long long& m_ready, unsigned long long& m_shade) {
     const unsigned long long done = __ballot(is_done);
     const unsigned long long idle = __ballot(is_idle);
     const int n_done = __popcll(done);
@@ -411,9 +414,9 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
     const bool parks = served && is_done;
     uint32_t slot = 0;
     if (served) slot = V.tbl[req];
-    uint32_t got[POOL_WORDS];
+    uint32_t got[W];
 #pragma unroll
-    for (int w = 0; w < POOL_WORDS; w++) got[w] = rec[w];
+    for (int w = 0; w < W; w++) got[w] = rec[w];
     if (takes) pool_load(V, slot, got);          // read the READY record before overwriting its slot
     if (parks) {
         pool_store(V, slot, rec);
@@ -422,7 +425,7 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
         V.sstate[slot] = SL_EMPTY;
     }
 #pragma unroll
-    for (int w = 0; w < POOL_WORDS; w++) rec[w] = got[w];
+    for (int w = 0; w < W; w++) rec[w] = got[w];
     const uint32_t st = V.sstate[lane];
     m_ready = __ballot(st == SL_READY);
     m_shade = __ballot(st == SL_HIT || st == SL_MISS);
@@ -437,8 +440,14 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
 // so the march loop stays (nearly) full; shading runs on the SLOTS (lane s <-> slot s) only when
 // >= shade_lanes of them wait, so it runs on (nearly) full waves too.  Slots freed by finished
 // samples are refilled with fresh pixel-samples.  Wave-private: no cross-wave synchronisation.
-enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_IDX, F_BOUNCE, F_KEY, F_CNT, F_ITEM, F_COUNT };
-static_assert(F_COUNT == POOL_WORDS, "trace record must fill the pool record");
+// F_META packs the nearest-object index (5 bits), the bounce number (11 bits) and the RNG draw count (16 bits):
+// the host falls back to scheduler 0 for MAX_RAYTRACE > 2047 (a path draws < 8 numbers per bounce).
+enum { F_OX = 0, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_CR, F_CG, F_CB, F_TEVAL, F_META, F_KEY, F_ITEM, F_COUNT };
+static_assert(F_COUNT <= POOL_WORDS, "trace record must fit the pool record");
+RT_D uint32_t pack_meta(int idx, int bounce, uint32_t cnt) { return (uint32_t)idx | ((uint32_t)bounce << 5) | (cnt << 16); }
+RT_D int meta_idx(uint32_t m) { return (int)(m & 31u); }
+RT_D int meta_bounce(uint32_t m) { return (int)((m >> 5) & 2047u); }
+RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 
 // Waves per SIMD the box instances are compiled for.  The kernel is latency-bound per wave (PMC at 4
 // waves: a wave issues during 44 % of its cycles, waits on s_waitcnt 27 %, on the issue arbiter
@@ -463,8 +472,8 @@ trace_paths_pool(const Params P) {
     __shared__ ObjFull lds_obj[NOBJ > 0 ? NOBJ : MAX_OBJ];
     __shared__ uint32_t pool_all[4][F_COUNT][64];
     __shared__ float save_all[(KIND == KIND_BOXES || KIND == KIND_GENERIC) ? 4 : 1][7][64];   // marching state parked during shading
-    __shared__ uint32_t sstate_all[4][64];
     __shared__ uint32_t tbl_all[4][64];
+    __shared__ uint32_t sstate_all[4][64];
     stage_objects(P, lds_obj);
 
     const int lane = threadIdx.x & 63;
@@ -483,8 +492,7 @@ trace_paths_pool(const Params P) {
     L.steps_left = 0;
     // the marching ray's bookkeeping (travels with the ray through the pool)
     vec3 a_col = mk(0, 0, 0);
-    int a_bounce = 0;
-    uint32_t a_key = 0, a_cnt = 0, a_item = 0;
+    uint32_t a_meta = 0, a_key = 0, a_item = 0;   // a_meta: bounce and draw count, packed like F_META
     // work counters kept wave-uniform (scalar registers, scalar adds of ballot popcounts) where the
     // control flow allows it: the per-lane v_add per march step and 3 VGPRs go away
     uint32_t w_steps = 0, w_raycasts = 0, w_hits = 0, w_samples = 0, w_sky = 0;
@@ -538,10 +546,11 @@ trace_paths_pool(const Params P) {
                     R.d = mk(u2f(pool[F_DX][lane]), u2f(pool[F_DY][lane]), u2f(pool[F_DZ][lane]));
                     R.col = mk(u2f(pool[F_CR][lane]), u2f(pool[F_CG][lane]), u2f(pool[F_CB][lane]));
                     R.t_eval = u2f(pool[F_TEVAL][lane]);
-                    R.idx = (int)pool[F_IDX][lane];
-                    R.bounce = (int)pool[F_BOUNCE][lane];
+                    const uint32_t meta = pool[F_META][lane];
+                    R.idx = meta_idx(meta);
+                    R.bounce = meta_bounce(meta);
+                    R.cnt = meta_cnt(meta);
                     R.key = pool[F_KEY][lane];
-                    R.cnt = pool[F_CNT][lane];
                     R.item = pool[F_ITEM][lane];
                     if (KIND != KIND_BUNNY) {
                         if (st == SL_HIT) {
@@ -597,10 +606,8 @@ trace_paths_pool(const Params P) {
                     pool[F_DX][lane] = f2u(R.d.x); pool[F_DY][lane] = f2u(R.d.y); pool[F_DZ][lane] = f2u(R.d.z);
                     pool[F_CR][lane] = f2u(R.col.x); pool[F_CG][lane] = f2u(R.col.y); pool[F_CB][lane] = f2u(R.col.z);
                     pool[F_TEVAL][lane] = f2u(R.t_eval);
-                    pool[F_IDX][lane] = (uint32_t)R.idx;
-                    pool[F_BOUNCE][lane] = (uint32_t)R.bounce;
+                    pool[F_META][lane] = pack_meta(R.idx, R.bounce, R.cnt);
                     pool[F_KEY][lane] = R.key;
-                    pool[F_CNT][lane] = R.cnt;
                     pool[F_ITEM][lane] = R.item;
                     st = resumed == ST_HIT ? SL_HIT : SL_MISS;
                 }
@@ -608,9 +615,8 @@ trace_paths_pool(const Params P) {
                     pool[F_OX][lane] = f2u(R.o.x); pool[F_OY][lane] = f2u(R.o.y); pool[F_OZ][lane] = f2u(R.o.z);
                     pool[F_DX][lane] = f2u(R.d.x); pool[F_DY][lane] = f2u(R.d.y); pool[F_DZ][lane] = f2u(R.d.z);
                     pool[F_CR][lane] = f2u(R.col.x); pool[F_CG][lane] = f2u(R.col.y); pool[F_CB][lane] = f2u(R.col.z);
-                    pool[F_BOUNCE][lane] = (uint32_t)R.bounce;
+                    pool[F_META][lane] = pack_meta(0, R.bounce, R.cnt);
                     pool[F_KEY][lane] = R.key;
-                    pool[F_CNT][lane] = R.cnt;
                     pool[F_ITEM][lane] = R.item;
                     st = SL_READY;
                 }
@@ -630,14 +636,13 @@ trace_paths_pool(const Params P) {
         // ================================================================ dispatch: swap finished lanes with parked rays
         {
             const bool is_done = L.state == ST_HIT || L.state == ST_MISS;
-            uint32_t rec[POOL_WORDS];
+            uint32_t rec[F_COUNT];
             rec[F_OX] = f2u(L.o.x); rec[F_OY] = f2u(L.o.y); rec[F_OZ] = f2u(L.o.z);
             rec[F_DX] = f2u(L.d.x); rec[F_DY] = f2u(L.d.y); rec[F_DZ] = f2u(L.d.z);
             rec[F_CR] = f2u(a_col.x); rec[F_CG] = f2u(a_col.y); rec[F_CB] = f2u(a_col.z);
             rec[F_TEVAL] = f2u(L.t_eval);
-            rec[F_IDX] = (uint32_t)L.idx;
-            rec[F_BOUNCE] = (uint32_t)a_bounce;
-            rec[F_KEY] = a_key; rec[F_CNT] = a_cnt; rec[F_ITEM] = a_item;
+            rec[F_META] = (a_meta & ~31u) | (uint32_t)L.idx;
+            rec[F_KEY] = a_key; rec[F_ITEM] = a_item;
             const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
             if (r & 2) L.state = ST_IDLE;
             w_raycasts += (uint32_t)__popcll(__ballot((r & 1) != 0));
@@ -645,8 +650,8 @@ trace_paths_pool(const Params P) {
                 L.o = mk(u2f(rec[F_OX]), u2f(rec[F_OY]), u2f(rec[F_OZ]));
                 L.d = mk(u2f(rec[F_DX]), u2f(rec[F_DY]), u2f(rec[F_DZ]));
                 a_col = mk(u2f(rec[F_CR]), u2f(rec[F_CG]), u2f(rec[F_CB]));
-                a_bounce = (int)rec[F_BOUNCE];
-                a_key = rec[F_KEY]; a_cnt = rec[F_CNT]; a_item = rec[F_ITEM];
+                a_meta = rec[F_META];
+                a_key = rec[F_KEY]; a_item = rec[F_ITEM];
                 march_init(P, L);
             }
         }
