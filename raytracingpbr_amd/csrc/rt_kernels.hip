@@ -458,8 +458,10 @@ RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 //   6 waves (80, 27 spills)       132.1 ms / 115 GB     7 waves (72, 51 spills) 138.0 ms
 // 5 is the default: the 6-wave build saves and restores the marching lanes' state around every
 // shading pass through scratch (100 GB per launch) for 4 % more speed.  The marching ray's origin,
-// direction and last distance are parked in LDS during shading (LDS has room for 7 dwords per lane at
-// 6 blocks per CU); build with -DRT_POOL_WAVES=6 to get the faster, scratch-heavy variant.
+// direction and last distance are parked in LDS during shading (7 dwords per lane).  Parking ALL of the
+// marching state (11 dwords, possible with 13-word records and the rank table aliased) does not help
+// the 80-register build: what it spills around the shading pass is then shading's own temporaries and
+// the marching ray's bookkeeping.  Build with -DRT_POOL_WAVES=6 to get the faster, scratch-heavy variant.
 #ifndef RT_POOL_WAVES
 #define RT_POOL_WAVES 5
 #endif
