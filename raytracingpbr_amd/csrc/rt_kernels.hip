@@ -92,7 +92,7 @@ struct PathRay {
 // returns true if the path continues with another raycast.
 template <int KIND, bool HAVE_NORMAL = false>
 RT_D bool shade_hit(const Params& P, const ObjFull* lds_obj, PathRay& R, vec3 given_normal = vec3{0, 0, 0}) {
-    const ObjFull o = lds_obj[R.idx];
+    const ObjFull& o = lds_obj[R.idx];   // read field by field where it is used (see surface_interaction)
     vec3 pos = fma3(R.t_eval, R.d, R.o);
     surface_interaction<KIND, HAVE_NORMAL>(P, o, pos, R.o, R.d, R.col, R.key, R.cnt, given_normal);
     float intensity = brightness(R.col);
@@ -451,19 +451,16 @@ RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 
 // Waves per SIMD the box instances are compiled for.  The kernel is latency-bound per wave (PMC at 4
 // waves: a wave issues during 44 % of its cycles, waits on s_waitcnt 27 %, on the issue arbiter
-// 29 %), so more resident waves pay even when the register cap costs a few spills.  Measured on the
-// headline frame (pool kernel time / HBM-side bytes per launch, of which 18 GB are staging stores
-// and primary records):
-//   4 waves (116 VGPRs, no spill) 147.1 ms / 18 GB      5 waves (96, 14 spills) 137.4 ms / 23 GB
-//   6 waves (80, 27 spills)       132.1 ms / 115 GB     7 waves (72, 51 spills) 138.0 ms
-// 5 is the default: the 6-wave build saves and restores the marching lanes' state around every
-// shading pass through scratch (100 GB per launch) for 4 % more speed.  The marching ray's origin,
-// direction and last distance are parked in LDS during shading (7 dwords per lane).  Parking ALL of the
-// marching state (11 dwords, possible with 13-word records and the rank table aliased) does not help
-// the 80-register build: what it spills around the shading pass is then shading's own temporaries and
-// the marching ray's bookkeeping.  Build with -DRT_POOL_WAVES=6 to get the faster, scratch-heavy variant.
+// 29 %), so more resident waves pay.  Measured on the headline frame (pool kernel time / HBM-side
+// bytes per launch, of which 18 GB are staging stores and primary records):
+//   4 waves (116 VGPRs)            147.1 ms / 18 GB      5 waves (96 VGPRs, no spill)  137.9 ms / 19 GB
+//   6 waves (80 VGPRs, 13 spills)  132.4 ms / 23 GB      7 waves: LDS (23.5 KB per block) allows only 6
+// Two things keep the 80-register build cheap: the marching ray's origin, direction and last distance
+// are parked in LDS during shading (7 dwords per lane), and the material is fetched after the normal
+// (compiler barrier in surface_interaction).  Without the barrier the 6-wave build saved and restored
+// 13 registers around every shading pass through scratch: 100 GB of extra traffic per launch.
 #ifndef RT_POOL_WAVES
-#define RT_POOL_WAVES 5
+#define RT_POOL_WAVES 6
 #endif
 #ifndef RT_POOL_WAVES_GENERIC
 #define RT_POOL_WAVES_GENERIC 5   // 114 -> 96 VGPRs, 13 spills: C4 (Tokyo IBL 4K) trace kernel 196 -> 180 ms; 6 waves: 187
