@@ -454,7 +454,7 @@ RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 // 29 %), so more resident waves pay.  Measured on the headline frame (pool kernel time / HBM-side
 // bytes per launch, of which 18 GB are staging stores and primary records):
 //   4 waves (116 VGPRs)            147.1 ms / 18 GB      5 waves (96 VGPRs, no spill)  137.9 ms / 19 GB
-//   6 waves (80 VGPRs, 13 spills)  132.4 ms / 23 GB      7 waves: LDS (23.5 KB per block) allows only 6
+//   6 waves (80 VGPRs, 13 spills)  132.4 ms / 23 GB      7 waves (72, 18 spills; rank table aliased so that LDS fits) 131.5 ms / 29 GB
 // Two things keep the 80-register build cheap: the marching ray's origin, direction and last distance
 // are parked in LDS during shading (7 dwords per lane), and the material is fetched after the normal
 // (compiler barrier in surface_interaction).  Without the barrier the 6-wave build saved and restored
