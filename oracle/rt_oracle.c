@@ -386,7 +386,7 @@ static void gen_ray(const struct rto_ctx* c, const cam_frame* f, int px, int py,
 
 /* ------------------------------------------------------------------ complete-path sample
  * cornell_box_v3/pathtracer.py:81-106 raytrace + renderer.py:31-36 */
-static v3 sample_complete(struct rto_ctx* c, const cam_frame* f, int px, int py, uint32_t sidx, rtpbr_counters* ctr) {
+static v3 sample_complete_n(struct rto_ctx* c, const cam_frame* f, int px, int py, uint32_t sidx, rtpbr_counters* ctr, uint32_t* draws) {
     const rtpbr_config* g = &c->cfg;
     uint32_t key = rto_rng_key(g->seed, (uint32_t)px, (uint32_t)py, sidx), cnt = 0;
     ray_t ray;
@@ -414,7 +414,11 @@ static v3 sample_complete(struct rto_ctx* c, const cam_frame* f, int px, int py,
         if (intensity < visible || visible < g->vis_lo || visible > g->vis_hi) break;
     }
     ctr->samples++;
+    if (draws) *draws = cnt;
     return ray.color;
+}
+static v3 sample_complete(struct rto_ctx* c, const cam_frame* f, int px, int py, uint32_t sidx, rtpbr_counters* ctr) {
+    return sample_complete_n(c, f, px, py, sidx, ctr, NULL);
 }
 
 /* ------------------------------------------------------------------ persistent-ray step
@@ -821,3 +825,56 @@ int rto_test_surface(struct rto_ctx* c, int obj, const float* pos, const float* 
     return (int)cnt;
 }
 float rto_test_bunny(const float* p) { return sd_bunny(v3_make(p[0], p[1], p[2])); }
+
+/* ---- hooks for tests/test_oracle_refpin.py (fixtures produced by the reference's own code) ---- */
+float rto_test_signed_distance(struct rto_ctx* c, int obj, const float* p) {
+    return signed_distance(c, &c->obj[obj], v3_make(p[0], p[1], p[2]));
+}
+/* one complete-path sample: colour, and {raycasts, march steps, RNG draws} */
+int rto_test_sample(struct rto_ctx* c, int px, int py, uint32_t sidx, float* color3, uint32_t* stats3) {
+    cam_frame f; camera_frame(c, &f);
+    rtpbr_counters k; memset(&k, 0, sizeof k);
+    uint32_t draws = 0;
+    v3 col = sample_complete_n(c, &f, px, py, sidx, &k, &draws);
+    color3[0] = col.x; color3[1] = col.y; color3[2] = col.z;
+    stats3[0] = (uint32_t)k.raycasts; stats3[1] = (uint32_t)k.march_steps; stats3[2] = draws;
+    return RTPBR_OK;
+}
+/* surface interaction with explicit incoming colour and RNG position (stream (px,py,sidx), draw n0).
+ * out12: direction, colour, origin, geometric normal as calc_normal returns it.  Returns the draw
+ * count after the call. */
+int rto_test_surface_at(struct rto_ctx* c, int obj, const float* pos, const float* origin, const float* dir, const float* color,
+                        int px, int py, uint32_t sidx, uint32_t n0, float* out12) {
+    ray_t r; r.origin = v3_make(origin[0], origin[1], origin[2]); r.direction = v3_make(dir[0], dir[1], dir[2]);
+    r.color = v3_make(color[0], color[1], color[2]); r.depth = 1;
+    uint32_t key = rto_rng_key(c->cfg.seed, (uint32_t)px, (uint32_t)py, sidx), cnt = n0;
+    v3 p = v3_make(pos[0], pos[1], pos[2]);
+    v3 n = calc_normal(c, &c->obj[obj], p);
+    surface_interaction(c, &r, &c->obj[obj], p, key, &cnt);
+    out12[0] = r.direction.x; out12[1] = r.direction.y; out12[2] = r.direction.z;
+    out12[3] = r.color.x; out12[4] = r.color.y; out12[5] = r.color.z;
+    out12[6] = r.origin.x; out12[7] = r.origin.y; out12[8] = r.origin.z;
+    out12[9] = n.x; out12[10] = n.y; out12[11] = n.z;
+    return (int)cnt;
+}
+void rto_test_sky(struct rto_ctx* c, const float* d, float* rgb) {
+    rtpbr_counters k; memset(&k, 0, sizeof k);
+    v3 s = sky_color(c, v3_make(d[0], d[1], d[2]), &k); rgb[0] = s.x; rgb[1] = s.y; rgb[2] = s.z;
+}
+/* src-form raycast: the ray origin moves; out: origin[3]; returns the object index */
+int rto_test_raycast_src(struct rto_ctx* c, const float* o, const float* d, float* origin3, int* hit, int* steps) {
+    rtpbr_counters k; memset(&k, 0, sizeof k);
+    ray_t r; r.origin = v3_make(o[0], o[1], o[2]); r.direction = v3_make(d[0], d[1], d[2]); r.color = v3_make(1, 1, 1); r.depth = 0;
+    int idx = raycast_src(c, &r, hit, &k);
+    origin3[0] = r.origin.x; origin3[1] = r.origin.y; origin3[2] = r.origin.z; *steps = (int)k.march_steps;
+    return idx;
+}
+/* camera ray drawn from draw n0 of stream (px,py,sidx): the src form reaches gen_ray after the roulette draw */
+int rto_test_get_ray_at(struct rto_ctx* c, int px, int py, uint32_t sidx, uint32_t n0, float* out6) {
+    cam_frame f; camera_frame(c, &f);
+    uint32_t key = rto_rng_key(c->cfg.seed, (uint32_t)px, (uint32_t)py, sidx), cnt = n0;
+    ray_t r; gen_ray(c, &f, px, py, key, &cnt, &r);
+    out6[0] = r.origin.x; out6[1] = r.origin.y; out6[2] = r.origin.z;
+    out6[3] = r.direction.x; out6[4] = r.direction.y; out6[5] = r.direction.z;
+    return (int)cnt;
+}

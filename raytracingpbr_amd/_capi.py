@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTPBR_HIP_LIB overrides the path (A/B of differently built HIP libraries); it must still be a HIP build
 HIP_LIB_PATH = os.environ.get("RTPBR_HIP_LIB") or os.path.join(_HERE, "csrc", "librtpbr_hip.so")
 
-# every symbol include/rtpbr.h declares (checked by tests/test_capi_symbols.py)
+# every symbol include/rtpbr.h declares (checked by tests/test_host_logic.py::test_hip_library_exports_every_declared_symbol)
 ENTRY_POINTS = [
     "create", "destroy", "last_error", "backend", "set_config", "set_scene", "get_scene",
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",

@@ -108,14 +108,9 @@ static int set_dev(rtpbr_ctx* c) {
 extern "C" const char* rtpbr_last_error(void) { return g_err; }
 extern "C" const char* rtpbr_backend(void) { return "hip-gfx950"; }
 
-extern "C" int rtpbr_create(int device, rtpbr_ctx** out) {
-    if (!out) return fail(RTPBR_EINVAL, "out is NULL");
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(RTPBR_EINVAL, "no such HIP device");
-    rtpbr_ctx* c = new rtpbr_ctx();
-    c->device = device;
-    HIP_TRY(hipSetDevice(device));
+extern "C" int rtpbr_destroy(rtpbr_ctx* c);
+static int create_resources(rtpbr_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->objfull, sizeof(ObjFull) * MAX_OBJ));
     HIP_TRY(hipMalloc(&c->work_counter, 64));
@@ -124,8 +119,23 @@ extern "C" int rtpbr_create(int device, rtpbr_ctx** out) {
     HIP_TRY(hipEventCreate(&c->ev_total0));
     HIP_TRY(hipEventCreate(&c->ev_total1));
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     c->n_cu = prop.multiProcessorCount;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_create(int device, rtpbr_ctx** out) {
+    if (!out) return fail(RTPBR_EINVAL, "out is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RTPBR_EINVAL, "no such HIP device");
+    rtpbr_ctx* c = new rtpbr_ctx();
+    c->device = device;
+    const int r = create_resources(c);
+    if (r != RTPBR_OK) {            // g_err already says which call failed; release whatever was created
+        rtpbr_destroy(c);
+        return r;
+    }
     *out = c;
     return RTPBR_OK;
 }
@@ -133,7 +143,7 @@ extern "C" int rtpbr_create(int device, rtpbr_ctx** out) {
 extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     if (!c) return RTPBR_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->image_buffer);
     (void)hipFree(c->image_pixels);
     (void)hipFree(c->ray_buffer);
@@ -148,9 +158,9 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(c->ev_total0);
-    (void)hipEventDestroy(c->ev_total1);
-    (void)hipStreamDestroy(c->stream);
+    if (c->ev_total0) (void)hipEventDestroy(c->ev_total0);
+    if (c->ev_total1) (void)hipEventDestroy(c->ev_total1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RTPBR_OK;
 }
@@ -176,11 +186,22 @@ static void update_tiles(rtpbr_ctx* c) {
     P.np = P.n_local_tiles * tw * th;
 }
 
+// Work items (padded local pixels x samples per launch) are 32-bit: a rank's padded pixel count must
+// leave room for at least one sample per launch plus the chunks the last waves claim past the end.
+static int check_local_pixels(int W, int H, int tw, int th, int world) {
+    if (world <= 1 || tw <= 0 || th <= 0) { tw = W; th = H; world = world < 1 ? 1 : world; }
+    const long long ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
+    const long long local = (ntx * nty + world - 1) / world;
+    if (local * tw * th > (1LL << 30)) return fail(RTPBR_EINVAL, "more than 2^30 (padded) pixels per rank: use more ranks or smaller frames");
+    return RTPBR_OK;
+}
+
 extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
     if (!c || !cfg) return fail(RTPBR_EINVAL, "null argument");
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 65535 || cfg->height > 65535)
         return fail(RTPBR_EINVAL, "resolution out of range (1..65535)");
     if (cfg->max_raymarch <= 0 || cfg->max_raytrace <= 0) return fail(RTPBR_EINVAL, "max_raymarch/max_raytrace must be > 0");
+    if (int r = check_local_pixels(cfg->width, cfg->height, c->tile_w, c->tile_h, c->world)) return r;
     if (int r = set_dev(c)) return r;
     bool realloc_buf = !c->have_cfg || c->cfg.width != cfg->width || c->cfg.height != cfg->height;
     c->cfg = *cfg;
@@ -454,7 +475,10 @@ extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world
     c->tile_h = th;
     c->rank = rank;
     c->world = world;
-    if (c->have_cfg) update_tiles(c);
+    if (c->have_cfg) {
+        if (int r = check_local_pixels(c->cfg.width, c->cfg.height, tw, th, world)) return r;
+        update_tiles(c);
+    }
     return RTPBR_OK;
 }
 
@@ -494,23 +518,19 @@ static int ensure_staging(rtpbr_ctx* c, size_t items, bool split) {
     return RTPBR_OK;
 }
 
-static hipEvent_t next_primary_event(rtpbr_ctx* c) {
-    if (c->evp_used == (int)c->evp.size()) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        c->evp.push_back(e);
+// next event of a reusable pool; a failed hipEventCreate is reported, never recorded
+static int next_event_of(std::vector<hipEvent_t>& pool, int& used, hipEvent_t* out) {
+    if (used == (int)pool.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        pool.push_back(e);
     }
-    return c->evp[c->evp_used++];
+    *out = pool[used++];
+    return RTPBR_OK;
 }
-
-static hipEvent_t next_event(rtpbr_ctx* c) {
-    if (c->ev_used == (int)c->ev.size()) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        c->ev.push_back(e);
-    }
-    return c->ev[c->ev_used++];
-}
+#define NEXT_EVENT(pool, used, var)                                   \
+    hipEvent_t var = nullptr;                                         \
+    if (int r_ = next_event_of(pool, used, &var)) return r_
 
 static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
     int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->P.box_sig, c->scheduler < 0 ? 1 : c->scheduler);
@@ -593,7 +613,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         while (left > 0) {
             int steps = (int)(left < 256 ? left : 256);
             P.sample_base = c->sample_base;
-            hipEvent_t a = next_event(c), b = next_event(c);
+            NEXT_EVENT(c->ev, c->ev_used, a);
+            NEXT_EVENT(c->ev, c->ev_used, b);
             HIP_TRY(hipEventRecord(a, c->stream));
             const bool use_pool = c->scheduler == 1 || (c->scheduler < 0 && P.np >= (1 << 20));
             if (use_pool) {
@@ -626,7 +647,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             long long kmax = c->staging_bytes / per_spp;
             if (kmax < 1) kmax = 1;
             // keep total_items within 32 bits
-            long long k32 = 0xFFFFFFFFLL / (long long)P.np - 1;
+            // (minus the chunks the last waves claim past the end: the work counter must not wrap)
+            long long k32 = (0xFFFFFFFFLL - (64LL << 20)) / (long long)P.np;
+            if (k32 < 1) k32 = 1;
             if (kmax > k32) kmax = k32;
             int K = (int)(left < kmax ? left : kmax);
             // the extra launch has a fixed cost of ~0.3 ms: below ~8 M items the fused kernel is faster
@@ -646,12 +669,14 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             P.chunk = (uint32_t)chunk;
             HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
             if (split) {
-                hipEvent_t pa = next_primary_event(c), pb = next_primary_event(c);
+                NEXT_EVENT(c->evp, c->evp_used, pa);
+                NEXT_EVENT(c->evp, c->evp_used, pb);
                 HIP_TRY(hipEventRecord(pa, c->stream));
                 launch_primary(P, c->kind, c->n_cu, c->stream);
                 HIP_TRY(hipEventRecord(pb, c->stream));
             }
-            hipEvent_t a = next_event(c), b = next_event(c);
+            NEXT_EVENT(c->ev, c->ev_used, a);
+            NEXT_EVENT(c->ev, c->ev_used, b);
             HIP_TRY(hipEventRecord(a, c->stream));
             launch_trace(P, c->kind, grid, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
@@ -860,7 +885,8 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
         long long per_spp = (long long)c->P.np * (long long)(sizeof(float4) + (split_ok ? sizeof(float2) : 0));
         long long kmax = c->staging_bytes / per_spp;
-        long long k32 = 0xFFFFFFFFLL / (long long)c->P.np - 1;
+        long long k32 = (0xFFFFFFFFLL - (64LL << 20)) / (long long)c->P.np;
+        if (k32 < 1) k32 = 1;
         if (kmax > k32) kmax = k32;
         if (kmax < 1) kmax = 1;
         const long long K = value < kmax ? value : kmax;

@@ -372,6 +372,16 @@ struct PoolView {
     uint32_t* tbl;          // rank -> slot table for the matching
 };
 
+// Wave-private LDS data passes between lanes of ONE wave (rank table, slot states, pool records).  The
+// hardware executes a wave's LDS instructions in order; this fence pins the same order for the compiler
+// (no reordering of may-alias LDS accesses across it) and costs no instruction.
+RT_D void lds_wave_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 RT_D int wave_rank(unsigned long long m) {   // number of set bits below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -407,6 +417,7 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
     // slot side: READY slots first, then free slots, listed by rank
     if ((m_ready >> lane) & 1ull) V.tbl[wave_rank(m_ready)] = (uint32_t)lane;
     else if ((m_free >> lane) & 1ull) V.tbl[n_ready + wave_rank(m_free)] = (uint32_t)lane;
+    lds_wave_fence();   // the table is read by other lanes of this wave
     // lane side: finished lanes first, then idle lanes
     const int req = is_done ? wave_rank(done) : n_done + wave_rank(idle);
     const bool served = (is_done || is_idle) && req < n_ready + n_free;
@@ -418,6 +429,7 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
 #pragma unroll
     for (int w = 0; w < W; w++) got[w] = rec[w];
     if (takes) pool_load(V, slot, got);          // read the READY record before overwriting its slot
+    lds_wave_fence();
     if (parks) {
         pool_store(V, slot, rec);
         V.sstate[slot] = done_state;
@@ -426,6 +438,7 @@ RT_D int pool_swap(const PoolView& V, int lane, bool is_done, bool is_idle, uint
     }
 #pragma unroll
     for (int w = 0; w < W; w++) rec[w] = got[w];
+    lds_wave_fence();   // slot states written by the lanes that parked / took
     const uint32_t st = V.sstate[lane];
     m_ready = __ballot(st == SL_READY);
     m_shade = __ballot(st == SL_HIT || st == SL_MISS);
@@ -1157,7 +1170,7 @@ __global__ void unpack_tiles_kernel(const Params P, const float4* src) {
     if (pixel_of(P, q, x, y)) P.image_buffer[(size_t)x * P.cfg.height + y] = src[q];
 }
 
-// test hook: evaluate one of the exact math functions on the device (tests/test_gpu_math.py)
+// test hook: evaluate one of the exact math functions on the device (tests/test_gpu_parity.py::test_exact_math_functions_match_oracle_bitwise)
 __global__ void math_probe(int op, const float* a, const float* b, float* out, float* out2, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1223,6 +1236,15 @@ void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st) {
     }
     if (P.cull_ok && P.box_sig == 0 && kind == KIND_BOXES && P.n_obj < 8) {
         hipLaunchKernelGGL((primary_rays<KIND_BOXES, 8>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        return;
+    }
+    if (!P.cull_ok) {
+        // the host could not bound the scene (non-finite / huge extent, steep cone, > 8 shapes): lock-step march
+        // without culling; the NOBJ = 0 instances have no nearest_culled branch
+        if (kind == KIND_BOXES) hipLaunchKernelGGL((primary_rays<KIND_BOXES, 0>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        else if (kind == KIND_BUNNY) hipLaunchKernelGGL((primary_rays<KIND_BUNNY, 0>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        else if (kind == KIND_MIXED) hipLaunchKernelGGL((primary_rays<KIND_MIXED, 0>), dim3((unsigned)grid), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((primary_rays<KIND_GENERIC, 0>), dim3((unsigned)grid), dim3(256), 0, st, P);
         return;
     }
     RT_DISPATCH_KIND(primary_rays, hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), 0, st, P));

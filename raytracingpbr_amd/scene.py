@@ -87,11 +87,12 @@ def src_scene(aspect=768 / 432, tokyo=False):
     return Scene(objs, False, cam, "tokyo" if tokyo else "src")
 
 
-def bunny(aspect=1920 / 1080, chrome=False):
-    """Neural-SDF bunny; bunny_sdf_glass.py:221-225 / bunny_sdf.py:219-221."""
+def bunny(aspect=1920 / 1080, chrome=False, v2=False):
+    """Neural-SDF bunny; bunny_sdf_glass.py:221-225 / bunny_sdf.py:219-221 /
+    bunny_sdf_v2.py (chrome, camera at z = 4: bunny_sdf_v2.py:437)."""
     if chrome:
         mat = Material(_v((1, 1, 1), 0.9), vec3(1), 0, 1, 0, 2.950)
-        cam = Camera((0, 0, 5), (0, 0, 1), (0, 1, 0), 30, aspect, 0.01, 4)
+        cam = Camera((0, 0, 4 if v2 else 5), (0, 0, 1), (0, 1, 0), 30, aspect, 0.01, 4)
     else:
         mat = Material(_v((1, 1, 1), 0.9), vec3(1), 0, 0, 1, 1.500)
         cam = Camera((0, 0, 4), (0, 0, 1), (0, 1, 0), 30, aspect, 0.03, 4)
