@@ -176,3 +176,42 @@ def test_rotation_signature_and_packed_table():
     blk = tab.reshape(8, 16)
     assert np.array_equal(blk[0, :3], np.array([0, 0, -10], np.float32)) and np.array_equal(blk[0, 3:12], np.eye(3, dtype=np.float32).ravel())
     assert blk[:, 15].view(np.int32).tolist() == [int(rt.SHAPE.BOX)] * 8
+
+
+def test_smooth_camera_moving_refresh_contract():
+    """src/camera.py:82-112: pose eases by clamp(velocity*dt,0,1) of the difference per frame; moving = any
+    component still differs by > 1e-3 (measured BEFORE the step); src/renderer.py:26-27 refreshes while moving."""
+    from raytracingpbr_amd.camera import SmoothCamera
+    s = SmoothCamera().init((0, -0.2, 4.0))
+    assert s.update(1 / 60, (0, -0.2, 4.0), (0, 0, 1), (0, 1, 0)) is False and s.frame == 1
+    moved = []
+    for _ in range(200):
+        moved.append(s.update(1 / 60, (1.0, -0.2, 4.0), (0, 0, 1), (0, 1, 0)))
+    assert moved[0] is True and moved[-1] is False                 # converges geometrically, then comes to rest
+    n = moved.index(False)
+    assert all(moved[:n]) and not any(moved[n:])
+    # one step covers 10/60 of the remaining distance: after k steps the residual is (5/6)^k
+    t = SmoothCamera().init((0, 0, 0))
+    t.update(1 / 60, (6.0, 0, 0), (0, 0, 1), (0, 1, 0))
+    assert abs(float(t.position[0]) - 1.0) < 1e-6
+    # dt large: clamp to 1 -> jumps to the target
+    t.update(1.0, (6.0, 0, 0), (0, 0, 1), (0, 1, 0))
+    assert float(t.position[0]) == 6.0
+
+
+def test_render_interactive_frame_refreshes_while_moving():
+    from raytracingpbr_amd import Config, src_scene
+    from raytracingpbr_amd.camera import SmoothCamera, render_interactive_frame
+    from raytracingpbr_amd.ibl import synthetic_env
+    from oracle_backend import OracleRenderer
+    r = OracleRenderer(src_scene(aspect=48 / 27), Config.src(48, 27, 0))
+    r.set_env(synthetic_env(64, 32), 1.4, 2.2)
+    s = SmoothCamera().init((0, -0.2, 4.0))
+    counts = []
+    for f in range(40):
+        tgt = (0.5, -0.2, 4.0) if 5 <= f else (0, -0.2, 4.0)
+        s.update(1 / 60, tgt, (0, 0, 1), (0, 1, 0))
+        render_interactive_frame(r, s, refreshing=(f == 0))
+        counts.append(float(r.image_buffer[..., 3].max()))
+    # deposits accumulate while at rest, drop to (almost) nothing each frame while the pose moves, grow again after
+    assert counts[4] >= 1 and min(counts[6:20]) <= 1 and counts[-1] >= counts[25]

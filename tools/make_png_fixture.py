@@ -17,3 +17,9 @@ bm = img.reshape(16, 32, 16, 32, 3).mean(axis=(1, 3)).astype(np.float32)
 out = os.path.join(ROOT, "tests", "golden", "cornell_taichi_png_blockmeans.npy")
 np.save(out, bm)
 print(out, bm.shape, bm.mean())
+
+# full-resolution copy (uint8, image orientation) for the per-pixel GPU comparison
+# (tests/test_gpu_refimage.py): result DATA of the reference, 512x512x3 bytes
+out8 = os.path.join(ROOT, "tests", "golden", "cornell_taichi_png_u8.npz")
+np.savez_compressed(out8, rgb=np.asarray(Image.open(src).convert("RGB"), dtype=np.uint8))
+print(out8, os.path.getsize(out8))
