@@ -54,7 +54,9 @@ def test_animation_driver_on_the_hip_renderer(tmp_path):
     case.setup(g)
     case.setup(o)
     frames = [0, 30, 60, 119]
-    paths = render_animation(g, frames, spp=2, out_dir=str(tmp_path))
+    w = Renderer(case.scene, case.cfg)              # (the driver continues the sample counter across frames and calls)
+    case.setup(w)
+    paths = render_animation(w, frames, spp=2, out_dir=str(tmp_path))
     assert [os.path.basename(q) for q in paths] == ["frame_%04d.png" % f for f in frames]
     got = render_animation(g, frames, spp=2)
     want = render_animation(o, frames, spp=2)
