@@ -514,7 +514,7 @@ static v3 tone_map(const rtpbr_config* g, const float* b) {
  *   layer 2: 4 blocks x {4 mat4, bias[4]}                     (272)  f2k = sin(sum_j f1j @ M_kj + b)/1.4 + f1k
  *   output : 4 x vec4 + bias                                   (17)
  * v @ M is the row-vector product: (v@M)_j = sum_i v_i M_ij.
- * Sums are evaluated as fma chains and the activations with rto_sin_pi (exactly specified). */
+ * Sums are evaluated as fma chains (order: see below) and the activations with rto_sin_pi (exactly specified). */
 static float sd_bunny(v3 p) {
     float len = v3_length(p);
     if (len > 1.0f) return len - 0.8f;
@@ -530,18 +530,23 @@ static float sd_bunny(v3 p) {
             f0[k * 4 + j] = rto_sin_pi(a + b[12 + j]);
         }
     }
-    /* layers 1, 2: out_kj = sin(sum_m sum_i v_mi * M_m[i][j] + bias) [/1.4] + in_kj; the 16-term
-     * sum is one fma chain in (m, i) order */
+    /* layers 1, 2: out_kj = sin(sum_m sum_i v_mi * M_m[i][j] + bias) [/1.4] + in_kj.  The 16-term sum is ONE fma
+     * chain from +0 in the order (i outer, m inner) — the order in which a 16x16x4 f32 MFMA that takes the previous
+     * layer's result registers directly as its B operand accumulates (rt_device.hpp bunny_mlp_wave); the division
+     * by the constant 1.4 is a multiplication by f32(1/1.4) (what LLVM's arcp fast-math flag, on by default in
+     * Taichi, makes of it).  Both are choices inside the rounding freedom the reference leaves;
+     * tests/test_oracle_refpin.py::test_bunny_sdf_and_raycast holds the result to 2e-6 of the reference's own code. */
     const float* src = f0; float* dst = f1;
     for (int layer = 0; layer < 2; layer++) {
         const float* lw = w + 64 + layer * 272;
         for (int k = 0; k < 4; k++) {
             const float* bw = lw + k * 68;
             for (int j = 0; j < 4; j++) {
-                float acc = 0.0f;   /* k-ordered fma chain from +0: what an f32 MFMA computes */
-                for (int t = 0; t < 16; t++) acc = fmaf(src[t], bw[(t >> 2) * 16 + (t & 3) * 4 + j], acc);
+                float acc = 0.0f;
+                for (int i = 0; i < 4; i++)
+                    for (int m = 0; m < 4; m++) acc = fmaf(src[m * 4 + i], bw[m * 16 + i * 4 + j], acc);
                 float sn = rto_sin_pi(acc + bw[64 + j]);
-                if (layer == 1) sn = sn / 1.4f;
+                if (layer == 1) sn = sn * 0.714285731f;          /* f32(1/1.4) */
                 dst[k * 4 + j] = sn + src[k * 4 + j];
             }
         }

@@ -461,8 +461,17 @@ extern "C" int rtpbr_set_shape_data(rtpbr_ctx* c, int shape, const float* data, 
     if (!c || !data) return fail(RTPBR_EINVAL, "null argument");
     if (shape != RTPBR_SHAPE_BUNNY || n != 625) return fail(RTPBR_EINVAL, "only the bunny MLP (625 weights) takes shape data");
     if (int r = set_dev(c)) return r;
+    // device layout: the hidden layers' matrices in chain order (rt_device.hpp): [k][i][m][j] <- caller's [k][m][i][j]
+    float dev[625];
+    memcpy(dev, data, sizeof dev);
+    for (int layer = 0; layer < 2; layer++)
+        for (int k = 0; k < 4; k++)
+            for (int m = 0; m < 4; m++)
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 4; j++)
+                        dev[64 + layer * 272 + k * 68 + i * 16 + m * 4 + j] = data[64 + layer * 272 + k * 68 + m * 16 + i * 4 + j];
     if (!c->bunny) HIP_TRY(hipMalloc(&c->bunny, 625 * sizeof(float)));
-    HIP_TRY(hipMemcpy(c->bunny, data, 625 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->bunny, dev, 625 * sizeof(float), hipMemcpyHostToDevice));
     c->P.bunny = c->bunny;
     return RTPBR_OK;
 }

@@ -42,10 +42,16 @@ typedef const __attribute__((address_space(4))) f16v* CF16Ptr;
 #define RT_PIN()
 #endif
 
-// one 16 -> 16 layer: out[k*4+j] = act(sum_t in[t]*W_k[(t>>2)*16+(t&3)*4+j] + b_k[j]) (/1.4) + in[k*4+j]
+// Device layout of the 625 weights (rtpbr_set_shape_data permutes the caller's array, layout of
+// tools/extract_bunny_weights.py, into this one): the hidden layers' 16x16 matrices are stored in CHAIN order,
+//   lw[k*68 + i*16 + m*4 + j] = M_{k,m}[i][j]      (caller: lw[k*68 + m*16 + i*4 + j])
+// because a neuron's 16-term sum is one fma chain in the order (i outer, m inner) — see bunny_mlp_wave.
+constexpr float INV_1_4 = 0.714285731f;   // f32(1/1.4): the reference's "/ 1.4" (bunny_sdf_glass.py:190-193), see rt_oracle.c
+
+// one 16 -> 16 layer: out[k*4+j] = act(chain_{i,m} in[m*4+i]*M_{k,m}[i][j] + b_k[j]) (*1/1.4) + in[k*4+j]
 template <bool DIV>
 RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
-    // block b = k*4 + m lives at lw + k*68 + m*16
+    // block b = k*4 + i (16 dwords [m][j]) lives at lw + k*68 + i*16
     f16v w0 = RT_LD16(lw, 0);
     f16v w1 = RT_LD16(lw, 16);
     RT_PIN();
@@ -53,18 +59,18 @@ RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
     for (int k = 0; k < 4; k++) {
         float acc[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int b = k * 4 + m;
+        for (int i = 0; i < 4; i++) {
+            const int b = k * 4 + i;
             // request block b+2 before block b is consumed
             const int nb = b + 2 < 16 ? b + 2 : 15;
             f16v w2 = RT_LD16(lw, (nb >> 2) * 68 + (nb & 3) * 16);
             RT_PIN();
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int m = 0; m < 4; m++) {
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
                     const float x = in[m * 4 + i];
-                    acc[jj] = fma_(x, w0[i * 4 + jj], (m == 0 && i == 0) ? 0.0f : acc[jj]);
+                    acc[jj] = fma_(x, w0[m * 4 + jj], (m == 0 && i == 0) ? 0.0f : acc[jj]);
                 }
             }
             w0 = w1;
@@ -74,7 +80,7 @@ RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
             float sn = sin_pi_(acc[jj] + bias[jj]);
-            if (DIV) sn = sn / 1.4f;
+            if (DIV) sn = sn * INV_1_4;
             out[k * 4 + jj] = sn + in[k * 4 + jj];
         }
     }
@@ -104,97 +110,117 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
 }
 
 // ---- wave-cooperative MLP on the matrix cores -------------------------------------------------
-// The two 16x16 layers (and the 4x16 input layer) are dense contractions over the 64 rays of a
-// wave, so they run as v_mfma_f32_16x16x4_f32: f32 in / f32 accumulate, bit-for-bit a k-ordered
-// fmaf chain from C (MI355X guide §3) — the same chain the VALU version and the oracle compute, so
-// results stay bit-identical.  Weights live in 9 VGPRs per lane as B fragments (loaded once per
-// kernel): no scalar-load stalls and half of the eval's arithmetic moves off the VALU.
-// Layouts (16x16x4): A: lane l holds A[i=l&15][k=l>>4];  B: lane l holds B[k=l>>4][j=l&15];
-// C/D: lane l, reg v holds D[i=(l>>4)*4+v][j=l&15].  i = ray within a block of 16, j = neuron.
-// Activations stay in D layout; between layers they pass through a wave-private LDS buffer
-// [t][ray] (row stride 80 words: conflict-free for both access patterns) to become A fragments.
+// The two 16x16 layers (and the 4x16 input layer) are dense contractions over the 64 rays of a wave, so they
+// run as v_mfma_f32_16x16x4_f32: f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain from C (MI355X
+// guide section 3) — the same chain the VALU version and the oracle compute, so results stay bit-identical.
+// TRANSPOSED product: D[i = neuron][j = ray] = sum_k W^T[i][k] * act[k][j], i.e. the WEIGHTS are the A operand
+// (lane l holds A[i = l&15][k = l>>4], 9 VGPRs per lane, loaded once per kernel) and the ACTIVATIONS the B
+// operand (lane l holds B[k = l>>4][j = l&15]).  The result layout — lane l, register v holds
+// D[i = 4*(l>>4) + v][j = l&15] — then IS the next layer's B operand: instruction kb of the next layer takes
+// register v = kb, i.e. lane group g contributes neuron 4g + kb as its k-th term.  No LDS round trip, no
+// transposition between layers; the price is the summation order (kb outer, g inner) = (i outer, m inner) in
+// the reference's (block m, row i) indexing, which the oracle adopts (rt_oracle.c sd_bunny).  Residual adds and
+// biases stay in the same registers.  Only the 3 input coordinates (ray -> lane group) and the 16 outputs per
+// ray (lane group -> ray) cross lanes, through a 4 KB wave-private LDS buffer.
+// The 64 rays are processed as two halves of 2 x 16 rays: two independent chains interleave (MFMA of one block
+// under the sines of the other) with 8 + 8 live activation / accumulator registers instead of 16 + 16.
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr int BUNNY_LDS_STRIDE = 80;
-constexpr int BUNNY_LDS_WORDS = 16 * BUNNY_LDS_STRIDE;
+constexpr int BUNNY_LDS_WORDS = 64 * 16;      // output staging [ray][16]; the input staging [3][64] aliases its upper half
+constexpr int BUNNY_LDS_IN = 512;
 
 struct BunnyFrag {
-    float b0;        // input layer  B[k][j], rows k = (wy, wz, wx, bias)
-    float b1[4];     // layer 1      B_kb[k][j] = W1[t = 4kb+k][j]
-    float b2[4];     // layer 2
-    float bias1, bias2;
+    float a0;        // input layer  A[i = neuron][k]: rows k = (wy, wz, wx, bias)
+    float a1[4];     // layer 1      A_kb[i][k = g] = W1(out i, in t = 4g + kb)
+    float a2[4];     // layer 2
 };
 
+// w = device layout (hidden layers in chain order, see above)
 RT_D void bunny_frag_load(const float* __restrict__ w, int lane, BunnyFrag& F) {
-    const int k = lane >> 4, j = lane & 15, blk = j >> 2, jj = j & 3;
-    F.b0 = w[blk * 16 + k * 4 + jj];
+    const int g = lane >> 4, io = lane & 15, blk = io >> 2, jj = io & 3;
+    F.a0 = w[blk * 16 + g * 4 + jj];
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
-        F.b1[kb] = w[64 + blk * 68 + kb * 16 + k * 4 + jj];
-        F.b2[kb] = w[64 + 272 + blk * 68 + kb * 16 + k * 4 + jj];
+        F.a1[kb] = w[64 + blk * 68 + kb * 16 + g * 4 + jj];          // M_{blk, m = g}[i = kb][jj]
+        F.a2[kb] = w[64 + 272 + blk * 68 + kb * 16 + g * 4 + jj];
     }
-    F.bias1 = w[64 + blk * 68 + 64 + jj];
-    F.bias2 = w[64 + 272 + blk * 68 + 64 + jj];
+}
+// the 2 x 16 biases, [layer][neuron], staged once per block in LDS (read as one b128 per lane group)
+RT_D void bunny_bias_stage(const float* __restrict__ w, float* bias_lds) {
+    if (threadIdx.x < 32) {
+        const int layer = threadIdx.x >> 4, n = threadIdx.x & 15;
+        bias_lds[threadIdx.x] = w[64 + layer * 272 + (n >> 2) * 68 + 64 + (n & 3)];
+    }
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_D f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+RT_D void bunny_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 #else
 RT_D f4v mfma4(float, float, f4v c) { return c; }
+RT_D void bunny_lds_fence() {}
 #endif
 
-// MUST be called by all 64 lanes (wave-uniform control flow).  lp = this lane's local point
-// (garbage allowed for lanes that do not need a result: rows are independent).  Returns the MLP
-// value for this lane's point.
-RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, float* lds, int lane, vec3 lp) {
-    const int li = lane & 15, lk = lane >> 4;
-    f4v act[4], acc[4];
-    // ---- input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b), one MFMA per block of 16 rays
-    lds[0 * BUNNY_LDS_STRIDE + lane] = lp.y;
-    lds[1 * BUNNY_LDS_STRIDE + lane] = lp.z;
-    lds[2 * BUNNY_LDS_STRIDE + lane] = -lp.x;
-    lds[3 * BUNNY_LDS_STRIDE + lane] = 1.0f;
+// MUST be called by all 64 lanes (wave-uniform control flow).  lp = this lane's local point (garbage allowed for
+// lanes that do not need a result: rays are independent).  Returns the MLP value for this lane's point.
+RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, float* lds, const float* bias_lds, int lane, vec3 lp) {
+    const int io = lane & 15, g = lane >> 4;
+    float* in = lds + BUNNY_LDS_IN;
+    in[0 * 64 + lane] = lp.y;
+    in[1 * 64 + lane] = lp.z;
+    in[2 * 64 + lane] = -lp.x;
+    bunny_lds_fence();
+    const f4v bias1 = *reinterpret_cast<const f4v*>(&bias_lds[4 * g]);
+    const f4v bias2 = *reinterpret_cast<const f4v*>(&bias_lds[16 + 4 * g]);
+#pragma nounroll
+    for (int h = 0; h < 2; h++) {
+        f4v act[2];
+        // ---- input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b); lane group g supplies component g of ray io
 #pragma unroll
-    for (int rb = 0; rb < 4; rb++) {
-        float a = lds[lk * BUNNY_LDS_STRIDE + rb * 16 + li];
-        f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
-        f4v d = mfma4(a, F.b0, z);
+        for (int r = 0; r < 2; r++) {
+            const float c = in[(g < 3 ? g : 0) * 64 + (2 * h + r) * 16 + io];
+            const float b = g < 3 ? c : 1.0f;
+            const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+            const f4v d = mfma4(F.a0, b, z);
 #pragma unroll
-        for (int v = 0; v < 4; v++) act[rb][v] = sin_pi_(d[v]);
-    }
-    // ---- two hidden layers
+            for (int v = 0; v < 4; v++) act[r][v] = sin_pi_(d[v]);
+        }
+        // ---- two hidden layers: the result registers are the next B operands
 #pragma unroll
-    for (int layer = 0; layer < 2; layer++) {
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++)   // D layout -> LDS [t = neuron][ray]
-            *reinterpret_cast<f4v*>(&lds[li * BUNNY_LDS_STRIDE + rb * 16 + lk * 4]) = act[rb];
-#pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
-            f4v c = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int layer = 0; layer < 2; layer++) {
+            f4v c[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
             for (int kb = 0; kb < 4; kb++) {
-                float a = lds[(kb * 4 + lk) * BUNNY_LDS_STRIDE + rb * 16 + li];
-                c = mfma4(a, layer == 0 ? F.b1[kb] : F.b2[kb], c);
-            }
-            acc[rb] = c;
-        }
-        const float bias = layer == 0 ? F.bias1 : F.bias2;
 #pragma unroll
-        for (int rb = 0; rb < 4; rb++) {
+                for (int r = 0; r < 2; r++) c[r] = mfma4(layer == 0 ? F.a1[kb] : F.a2[kb], act[r][kb], c[r]);
+            }
+            const f4v bias = layer == 0 ? bias1 : bias2;
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                float sn = sin_pi_(acc[rb][v] + bias);
-                if (layer == 1) sn = sn / 1.4f;
-                act[rb][v] = sn + act[rb][v];
+            for (int r = 0; r < 2; r++) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    float sn = sin_pi_(c[r][v] + bias[v]);
+                    if (layer == 1) sn = sn * INV_1_4;
+                    act[r][v] = sn + act[r][v];
+                }
             }
         }
+        // ---- back to lane = ray: [ray][neuron 4g .. 4g+3]
+#pragma unroll
+        for (int r = 0; r < 2; r++) *reinterpret_cast<f4v*>(&lds[((2 * h + r) * 16 + io) * 16 + 4 * g]) = act[r];
     }
-    // ---- output: back to lane = ray, 16-term chain with the (uniform) output weights
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++) *reinterpret_cast<f4v*>(&lds[li * BUNNY_LDS_STRIDE + rb * 16 + lk * 4]) = act[rb];
+    bunny_lds_fence();
     CFloatPtr ow = (CFloatPtr)wg + 64 + 544;
-    float sd = lds[lane] * ow[0];
+    f4v o[4];
 #pragma unroll
-    for (int t = 1; t < 16; t++) sd = fma_(lds[t * BUNNY_LDS_STRIDE + lane], ow[t], sd);
+    for (int q = 0; q < 4; q++) o[q] = *reinterpret_cast<const f4v*>(&lds[lane * 16 + 4 * q]);
+    bunny_lds_fence();    // the buffer is rewritten by the next call
+    float sd = o[0][0] * ow[0];
+#pragma unroll
+    for (int t = 1; t < 16; t++) sd = fma_(o[t >> 2][t & 3], ow[t], sd);
     return sd + ow[16];
 }
 
@@ -672,7 +698,7 @@ RT_D vec3 calc_normal(const Params& P, const ObjFull& o, vec3 p) {
 // rolled loop in calc_normal (tetrahedron offsets, signed distance of the one object), but the
 // four MLP evaluations are wave-cooperative, so ALL 64 lanes must call this (uniform flow);
 // lanes without a hit pass any position and ignore the result.
-RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, int lane, vec3 p) {
+RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, const float* bias_lds, int lane, vec3 p) {
     // the single object's transform comes from the kernarg table (scalar operands, no VGPRs)
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
@@ -689,7 +715,7 @@ RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, int
         vec3 e = world ? mk(ex * h, ey * h, ez * h) : mk(ex, ey, ez);
         vec3 l = world ? to_local<KIND_BUNNY>(P, o, q + e) : q + e * h;
         float len = length(l);
-        float sd = bunny_mlp_wave(F, P.bunny, lds, lane, l);
+        float sd = bunny_mlp_wave(F, P.bunny, lds, bias_lds, lane, l);
         float d = (len > 1.0f) ? len - 0.8f : sd;
         vec3 t = e * d;
         n = (i == 0 && world) ? t : n + t;

@@ -478,8 +478,11 @@ RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 #ifndef RT_POOL_WAVES_GENERIC
 #define RT_POOL_WAVES_GENERIC 5   // 114 -> 96 VGPRs, 13 spills: C4 (Tokyo IBL 4K) trace kernel 196 -> 180 ms; 6 waves: 187
 #endif
+#ifndef RT_POOL_WAVES_BUNNY
+#define RT_POOL_WAVES_BUNNY 4
+#endif
 template <int KIND, int NOBJ, uint32_t SIG = 0>
-__global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : KIND == KIND_GENERIC ? RT_POOL_WAVES_GENERIC : 1))
+__global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : KIND == KIND_GENERIC ? RT_POOL_WAVES_GENERIC : KIND == KIND_BUNNY ? RT_POOL_WAVES_BUNNY : 1))
 trace_paths_pool(const Params P) {
     __shared__ ObjFull lds_obj[NOBJ > 0 ? NOBJ : MAX_OBJ];
     __shared__ uint32_t pool_all[4][F_COUNT][64];
@@ -512,10 +515,15 @@ trace_paths_pool(const Params P) {
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
     bool b_pending = false;                         // bunny: position evaluated, MLP still to run
     vec3 b_lp = mk(0, 0, 0);
-    __shared__ float b_lds_all[(KIND == KIND_BUNNY) ? 4 * BUNNY_LDS_WORDS : 4];
+    __shared__ __attribute__((aligned(16))) float b_lds_all[(KIND == KIND_BUNNY) ? 4 * BUNNY_LDS_WORDS : 4];
+    __shared__ __attribute__((aligned(16))) float b_bias[32];
     float* b_lds = &b_lds_all[(KIND == KIND_BUNNY) ? wave * BUNNY_LDS_WORDS : 0];
     BunnyFrag b_frag = {};
-    if (KIND == KIND_BUNNY && P.bunny != nullptr) bunny_frag_load(P.bunny, lane, b_frag);
+    if (KIND == KIND_BUNNY && P.bunny != nullptr) {
+        bunny_frag_load(P.bunny, lane, b_frag);
+        bunny_bias_stage(P.bunny, b_bias);
+        __syncthreads();
+    }
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
 
@@ -577,7 +585,7 @@ trace_paths_pool(const Params P) {
                     // (uniform control flow); only the lanes whose slot holds a hit use the result
                     vec3 hp = fma3(R.t_eval, R.d, R.o);
                     vec3 nrm = mk(0, 0, 0);
-                    if (__any(st == SL_HIT)) nrm = bunny_normal_wave(P, b_frag, b_lds, lane, hp);
+                    if (__any(st == SL_HIT)) nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, lane, hp);
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
                     } else if (st == SL_MISS) {
@@ -697,7 +705,7 @@ trace_paths_pool(const Params P) {
                     }
                     if (__any(b_pending)) {
                         // all 64 lanes evaluate together on the matrix cores (uniform control flow)
-                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, lane, b_lp);
+                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp);
                         if (b_pending) {
                             march_update(P, L, 0, bunny_post_value(P, sd));
                             b_pending = false;
