@@ -295,6 +295,10 @@ int rtpbr_unpack_tiles(rtpbr_ctx* ctx, const void* device_src, int src_rank);
 
 /* Measurement hooks (SURVEY.md §5 tracing row, §8(d)). */
 int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking */
+/* One counter by name: the six above, plus "mlp_wave_evals" / "mlp_lane_evals" — passes of the wave-cooperative
+ * neural-SDF network (bunny_sdf_glass.py:149-203 on the matrix cores) and the ray evaluations they were needed for;
+ * their ratio / 64 is the lane utilisation of the MLP.  EINVAL for an unknown name. */
+int rtpbr_get_counter(rtpbr_ctx* ctx, const char* name, unsigned long long* out);
 /* Device time (HIP events on the context's stream) of the trace kernel launches and of
  * all kernels of the last rtpbr_sample() call, in milliseconds (blocking). */
 int rtpbr_last_sample_ms(rtpbr_ctx* ctx, float* trace_ms, float* total_ms, int* launches);

@@ -44,6 +44,7 @@ struct rto_ctx {
     int tile_w, tile_h, rank, world;
     uint32_t sample_base;                 /* samples (or bounce-steps) done since create */
     rtpbr_counters ctr;
+    unsigned long long mlp_evals;         /* of the last rto_sample() call */
     int threads;
 };
 
@@ -52,6 +53,7 @@ struct rto_ctx {
  * time through rto_set_bunny_weights() (tests load them from the committed data file). */
 static float g_bunny[625];
 static int g_bunny_set = 0;
+static __thread unsigned long long t_mlp_evals;      /* network evaluations by this thread (sd_bunny inside the unit sphere) */
 
 /* ------------------------------------------------------------------ Euler -> matrix
  * src/util.py:36-42 rotate(); examples: angle().  M = Rz @ Ry @ Rx, row major. */
@@ -519,6 +521,7 @@ static float sd_bunny(v3 p) {
     float len = v3_length(p);
     if (len > 1.0f) return len - 0.8f;
     if (!g_bunny_set) return len - 0.8f;
+    t_mlp_evals++;
     const float* w = g_bunny;
     float f0[16], f1[16], f2[16];
     /* layer 0: sin(p.y*wy + p.z*wz - p.x*wx + b), as one fma chain */
@@ -669,6 +672,7 @@ int rto_sample(struct rto_ctx* c, int n) {
     cam_frame f;
     camera_frame(c, &f);
     rtpbr_counters tot; memset(&tot, 0, sizeof tot);
+    unsigned long long mlp_total = 0;
     int persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
     int steps = persistent ? n * c->cfg.steps_per_launch : n;
     uint32_t base = c->sample_base;
@@ -678,6 +682,7 @@ int rto_sample(struct rto_ctx* c, int n) {
 #endif
     {
         rtpbr_counters ctr; memset(&ctr, 0, sizeof ctr);
+        t_mlp_evals = 0;
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
@@ -705,10 +710,12 @@ int rto_sample(struct rto_ctx* c, int n) {
         {
             tot.samples += ctr.samples; tot.raycasts += ctr.raycasts; tot.march_steps += ctr.march_steps;
             tot.hits += ctr.hits; tot.sky_lookups += ctr.sky_lookups; tot.deposits += ctr.deposits;
+            mlp_total += t_mlp_evals;
         }
     }
     c->sample_base = base + (uint32_t)steps;
     c->ctr = tot;
+    c->mlp_evals = mlp_total;
     return RTPBR_OK;
 }
 int rto_post_process(struct rto_ctx* c) {
@@ -752,6 +759,19 @@ int rto_write_buffer(struct rto_ctx* c, int which, const void* src, size_t nbyte
     memcpy(p, src, n); return RTPBR_OK;
 }
 int rto_get_counters(struct rto_ctx* c, rtpbr_counters* out) { *out = c->ctr; return RTPBR_OK; }
+int rto_get_counter(struct rto_ctx* c, const char* name, unsigned long long* out) {
+    if (!c || !name || !out) return fail(RTPBR_EINVAL, "null");
+    if (!strcmp(name, "samples")) *out = c->ctr.samples;
+    else if (!strcmp(name, "raycasts")) *out = c->ctr.raycasts;
+    else if (!strcmp(name, "march_steps")) *out = c->ctr.march_steps;
+    else if (!strcmp(name, "hits")) *out = c->ctr.hits;
+    else if (!strcmp(name, "sky_lookups")) *out = c->ctr.sky_lookups;
+    else if (!strcmp(name, "deposits")) *out = c->ctr.deposits;
+    else if (!strcmp(name, "mlp_lane_evals")) *out = c->mlp_evals;       /* the oracle evaluates ray by ray */
+    else if (!strcmp(name, "mlp_wave_evals")) *out = 0;
+    else return fail(RTPBR_EINVAL, "unknown counter");
+    return RTPBR_OK;
+}
 int rto_set_sample_base(struct rto_ctx* c, uint32_t base) { c->sample_base = base; return RTPBR_OK; }
 int rto_set_bunny_weights(const float* w, int n) {
     if (n != 625) return fail(RTPBR_EINVAL, "need 625 weights");

@@ -27,6 +27,7 @@ int rto_sync(struct rto_ctx* c);
 int rto_read_buffer(struct rto_ctx* c, int which, void* dst, size_t nbytes);
 int rto_write_buffer(struct rto_ctx* c, int which, const void* src, size_t nbytes);
 int rto_get_counters(struct rto_ctx* c, rtpbr_counters* out);
+int rto_get_counter(struct rto_ctx* c, const char* name, unsigned long long* out);
 /* oracle-only controls */
 int rto_set_threads(struct rto_ctx* c, int n);
 int rto_set_sample_base(struct rto_ctx* c, uint32_t base);

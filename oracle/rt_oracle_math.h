@@ -80,20 +80,28 @@ static inline void rto_sincosf(float a, float* s_out, float* c_out) {
 }
 static inline float rto_sinf(float a) { float s, c; rto_sincosf(a, &s, &c); return s; }
 
-/* ---- sin for the neural-SDF activations: reduction by pi (3-term Cody-Waite), one odd
- * degree-9 minimax polynomial on [-pi/2, pi/2] (max abs error 1.2e-7), sign from the parity of k.
- * 16 operations instead of 22; used 48 times per bunny SDF evaluation. ---- */
+/* ---- sin for the neural-SDF activations (48 per bunny SDF evaluation): 11 operations.
+ * k = round(a/pi) is formed by adding 1.5*2^23: the fma rounds a/pi to the nearest integer in one step and leaves k's
+ * parity in the lowest mantissa bit of t; reduction by pi in two Cody-Waite terms (3.140625 has 11 significant bits,
+ * so k*3.140625 is exact for |k| < 2^13; the second term carries pi - 3.140625 to 2^-35 absolute: fine for the
+ * |k| <= ~100 the MLP's pre-activations reach, error grows as 6e-11 |k|); one odd degree-9 minimax polynomial on
+ * [-pi/2, pi/2] (max abs error 1.2e-7); the sign is applied by ADDING parity << 31 to the bit pattern.
+ * Defined (deterministically) for every input; accurate for |a| < ~1e3.  tests/test_oracle_math.py pins it. */
 static inline float rto_sin_pi(float a) {
-    float kf = rintf(a * RTO_INV_PI);
-    int k = (int)kf;
+    const float magic = 12582912.0f;                       /* 1.5 * 2^23 */
+    float t = fmaf(a, RTO_INV_PI, magic);
+    float kf = t - magic;
     float r = fmaf(kf, -3.140625f, a);
-    r = fmaf(kf, -9.67502593994140625e-4f, r);
-    r = fmaf(kf, -1.509957990978376432e-7f, r);
+    r = fmaf(kf, -9.676535846665502e-4f, r);
     float r2 = r * r;
     float p = fmaf(fmaf(fmaf(2.6073803383042105e-06f, r2, -0.00019809493096545339f), r2, 0.008333046920597553f), r2,
                    -0.16666658222675323f);
     float s = fmaf(r * r2, p, r);
-    return (k & 1) ? -s : s;
+    uint32_t tb, sb;
+    memcpy(&tb, &t, 4); memcpy(&sb, &s, 4);
+    sb += tb << 31;
+    memcpy(&s, &sb, 4);
+    return s;
 }
 
 /* ---- exp: Cephes expf ---- */

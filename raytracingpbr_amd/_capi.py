@@ -23,7 +23,7 @@ ENTRY_POINTS = [
     "create", "destroy", "last_error", "backend", "set_config", "set_scene", "get_scene",
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",
     "read_buffer", "write_buffer", "packed_bytes", "pack_tiles", "unpack_tiles",
-    "get_counters", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
+    "get_counters", "get_counter", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
 ]
 
 
@@ -62,6 +62,7 @@ class CApi:
             "pack_tiles": (C.c_int, [p, p]),
             "unpack_tiles": (C.c_int, [p, p, C.c_int]),
             "get_counters": (C.c_int, [p, C.POINTER(Counters)]),
+            "get_counter": (C.c_int, [p, C.c_char_p, C.POINTER(C.c_uint64)]),
             "last_sample_ms": (C.c_int, [p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
             "last_primary_ms": (C.c_int, [p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
             "get_stream": (C.c_int, [p, C.POINTER(p)]),

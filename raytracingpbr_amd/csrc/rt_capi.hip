@@ -810,6 +810,26 @@ extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
     return RTPBR_OK;
 }
 
+// Named counters of the last rtpbr_sample() call: the six of rtpbr_counters plus "mlp_wave_evals" (passes of the
+// wave-cooperative neural-SDF MLP) and "mlp_lane_evals" (ray evaluations those passes were needed for).
+extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long long* out) {
+    if (!c || !name || !out) return fail(RTPBR_EINVAL, "null argument");
+    if (int r = set_dev(c)) return r;
+    Counters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!strcmp(name, "samples")) *out = h.samples;
+    else if (!strcmp(name, "raycasts")) *out = h.raycasts;
+    else if (!strcmp(name, "march_steps")) *out = h.march_steps;
+    else if (!strcmp(name, "hits")) *out = h.hits;
+    else if (!strcmp(name, "sky_lookups")) *out = h.sky_lookups;
+    else if (!strcmp(name, "deposits")) *out = h.deposits + c->deposits_host;
+    else if (!strcmp(name, "mlp_wave_evals")) *out = h.mlp_wave_evals;
+    else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
+    else return fail(RTPBR_EINVAL, "unknown counter %s", name);
+    return RTPBR_OK;
+}
+
 extern "C" int rtpbr_last_sample_ms(rtpbr_ctx* c, float* trace_ms, float* total_ms, int* launches) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (!c->timed) return fail(RTPBR_ESTATE, "no rtpbr_sample() call to time yet");

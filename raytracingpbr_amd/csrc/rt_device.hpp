@@ -46,7 +46,7 @@ typedef const __attribute__((address_space(4))) f16v* CF16Ptr;
 // tools/extract_bunny_weights.py, into this one): the hidden layers' 16x16 matrices are stored in CHAIN order,
 //   lw[k*68 + i*16 + m*4 + j] = M_{k,m}[i][j]      (caller: lw[k*68 + m*16 + i*4 + j])
 // because a neuron's 16-term sum is one fma chain in the order (i outer, m inner) — see bunny_mlp_wave.
-constexpr float INV_1_4 = 0.714285731f;   // f32(1/1.4): the reference's "/ 1.4" (bunny_sdf_glass.py:190-193), see rt_oracle.c
+constexpr float INV_1_4 = 0.714285731f;   // f32(1/1.4): the reference's "/ 1.4" (bunny_sdf_glass.py:190-193) as a multiplication
 
 // one 16 -> 16 layer: out[k*4+j] = act(chain_{i,m} in[m*4+i]*M_{k,m}[i][j] + b_k[j]) (*1/1.4) + in[k*4+j]
 template <bool DIV>
@@ -119,7 +119,7 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
 // D[i = 4*(l>>4) + v][j = l&15] — then IS the next layer's B operand: instruction kb of the next layer takes
 // register v = kb, i.e. lane group g contributes neuron 4g + kb as its k-th term.  No LDS round trip, no
 // transposition between layers; the price is the summation order (kb outer, g inner) = (i outer, m inner) in
-// the reference's (block m, row i) indexing, which the oracle adopts (rt_oracle.c sd_bunny).  Residual adds and
+// the reference's (block m, row i) indexing; the CPU checker uses the same order.  Residual adds and
 // biases stay in the same registers.  Only the 3 input coordinates (ray -> lane group) and the 16 outputs per
 // ray (lane group -> ray) cross lanes, through a 4 KB wave-private LDS buffer.
 // The 64 rays are processed as two halves of 2 x 16 rays: two independent chains interleave (MFMA of one block
@@ -694,31 +694,53 @@ RT_D vec3 calc_normal(const Params& P, const ObjFull& o, vec3 p) {
     }
 }
 
-// calc_normal for the single-bunny kind with the MLP on the matrix cores: same arithmetic as the
-// rolled loop in calc_normal (tetrahedron offsets, signed distance of the one object), but the
-// four MLP evaluations are wave-cooperative, so ALL 64 lanes must call this (uniform flow);
-// lanes without a hit pass any position and ignore the result.
-RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, const float* bias_lds, int lane, vec3 p) {
-    // the single object's transform comes from the kernarg table (scalar operands, no VGPRs)
+// calc_normal for the single-bunny kind with the MLP on the matrix cores: same arithmetic as the rolled loop in
+// calc_normal (tetrahedron offsets, signed distance of the one object), wave-cooperative: ALL 64 lanes call it.
+// `hit` = this lane's slot holds a hit at `p`.  Only some of the 64 slots hold hits when a shading pass runs, so the
+// (hit, offset) pairs are COMPACTED: pair j = 4*rank + e is evaluated by lane j & 63 of batch j >> 6 — one MLP pass
+// per 16 hits instead of four passes per shading pass.  Hit positions travel by ds_bpermute (rank -> lane table in
+// `tbl`, 64 words of wave-private LDS that are idle during shading), the four distances travel back the same way.
+RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, const float* bias_lds, uint32_t* tbl, int lane,
+                            bool hit, vec3 p, uint32_t& n_passes) {
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
-    const ObjM o = tab[0];
+    const ObjM o = tab[0];                 // the single object's transform: scalar operands
     const float h = P.cfg.normal_h;
     const bool world = P.cfg.normal_space == RTPBR_NORMAL_WORLD;
-    vec3 q = world ? p : to_local<KIND_BUNNY>(P, o, p);
+    const unsigned long long m = __ballot(hit);
+    const int n_hit = __popcll(m);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (hit) tbl[rank] = (uint32_t)lane;
+    bunny_lds_fence();
+    const int e_i = lane & 3;                       // tetrahedron offsets (1,-1,-1), (-1,-1,1), (-1,1,-1), (1,1,1)
+    const float ex = (e_i == 0 || e_i == 3) ? 1.0f : -1.0f, ey = (e_i >= 2) ? 1.0f : -1.0f, ez = (e_i & 1) ? 1.0f : -1.0f;
+    const vec3 e = world ? mk(ex * h, ey * h, ez * h) : mk(ex, ey, ez);
+    float d4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int n_batches = (n_hit + 15) >> 4;
+    for (int b = 0; b < n_batches; b++) {
+        const int hidx = b * 16 + (lane >> 2);
+        const int src = (int)tbl[hidx < n_hit ? hidx : 0];
+        const vec3 hp = mk(__shfl(p.x, src, 64), __shfl(p.y, src, 64), __shfl(p.z, src, 64));
+        const vec3 q = world ? hp : to_local<KIND_BUNNY>(P, o, hp);
+        const vec3 l = world ? to_local<KIND_BUNNY>(P, o, q + e) : q + e * h;
+        const float len = length(l);
+        const float sd = bunny_mlp_wave(F, P.bunny, lds, bias_lds, lane, l);
+        const float d = (len > 1.0f) ? len - 0.8f : sd;
+        const bool mine = hit && (rank >> 4) == b;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float v = __shfl(d, (4 * rank + k) & 63, 64);
+            d4[k] = mine ? v : d4[k];
+        }
+    }
+    n_passes += (uint32_t)n_batches;
     vec3 n = mk(0, 0, 0);
-#pragma nounroll
-    for (int i = 0; i < 4; i++) {
-        float ex = (i == 0 || i == 3) ? 1.0f : -1.0f;
-        float ey = (i >= 2) ? 1.0f : -1.0f;
-        float ez = (i & 1) ? 1.0f : -1.0f;
-        vec3 e = world ? mk(ex * h, ey * h, ez * h) : mk(ex, ey, ez);
-        vec3 l = world ? to_local<KIND_BUNNY>(P, o, q + e) : q + e * h;
-        float len = length(l);
-        float sd = bunny_mlp_wave(F, P.bunny, lds, bias_lds, lane, l);
-        float d = (len > 1.0f) ? len - 0.8f : sd;
-        vec3 t = e * d;
-        n = (i == 0 && world) ? t : n + t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float kx = (k == 0 || k == 3) ? 1.0f : -1.0f, ky = (k >= 2) ? 1.0f : -1.0f, kz = (k & 1) ? 1.0f : -1.0f;
+        const vec3 ek = world ? mk(kx * h, ky * h, kz * h) : mk(kx, ky, kz);
+        const vec3 t = ek * d4[k];
+        n = (k == 0 && world) ? t : n + t;
     }
     return normalize(n);
 }

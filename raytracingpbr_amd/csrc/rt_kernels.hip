@@ -484,9 +484,10 @@ RT_D uint32_t meta_cnt(uint32_t m) { return m >> 16; }
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256, (KIND == KIND_BOXES ? RT_POOL_WAVES : KIND == KIND_GENERIC ? RT_POOL_WAVES_GENERIC : KIND == KIND_BUNNY ? RT_POOL_WAVES_BUNNY : 1))
 trace_paths_pool(const Params P) {
-    __shared__ ObjFull lds_obj[NOBJ > 0 ? NOBJ : MAX_OBJ];
+    __shared__ ObjFull lds_obj[NOBJ > 0 ? NOBJ : (KIND == KIND_BUNNY ? 1 : MAX_OBJ)];   // KIND_BUNNY: exactly one object
     __shared__ uint32_t pool_all[4][F_COUNT][64];
-    __shared__ float save_all[(KIND == KIND_BOXES || KIND == KIND_GENERIC) ? 4 : 1][7][64];   // marching state parked during shading
+    constexpr bool PARK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
+    __shared__ float save_all[PARK ? 4 : 1][PARK ? 7 : 1][PARK ? 64 : 1];   // marching state parked during shading
     __shared__ uint32_t tbl_all[4][64];
     __shared__ uint32_t sstate_all[4][64];
     stage_objects(P, lds_obj);
@@ -511,6 +512,7 @@ trace_paths_pool(const Params P) {
     // work counters kept wave-uniform (scalar registers, scalar adds of ballot popcounts) where the
     // control flow allows it: the per-lane v_add per march step and 3 VGPRs go away
     uint32_t w_steps = 0, w_raycasts = 0, w_hits = 0, w_samples = 0, w_sky = 0;
+    uint32_t w_mlp_wave = 0, w_mlp_lane = 0;
     WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
     bool b_pending = false;                         // bunny: position evaluated, MLP still to run
@@ -585,7 +587,10 @@ trace_paths_pool(const Params P) {
                     // (uniform control flow); only the lanes whose slot holds a hit use the result
                     vec3 hp = fma3(R.t_eval, R.d, R.o);
                     vec3 nrm = mk(0, 0, 0);
-                    if (__any(st == SL_HIT)) nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, lane, hp);
+                    if (__any(st == SL_HIT)) {
+                        w_mlp_lane += 4u * (uint32_t)__popcll(__ballot(st == SL_HIT));
+                        nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, tbl_all[wave], lane, st == SL_HIT, hp, w_mlp_wave);
+                    }
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
                     } else if (st == SL_MISS) {
@@ -705,6 +710,8 @@ trace_paths_pool(const Params P) {
                     }
                     if (__any(b_pending)) {
                         // all 64 lanes evaluate together on the matrix cores (uniform control flow)
+                        w_mlp_wave += 1u;
+                        w_mlp_lane += (uint32_t)__popcll(__ballot(b_pending));
                         const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp);
                         if (b_pending) {
                             march_update(P, L, 0, bunny_post_value(P, sd));
@@ -730,6 +737,10 @@ trace_paths_pool(const Params P) {
         atomicAdd(&P.counters->deposits, tA >> 10);
     }
 #endif
+    if (KIND == KIND_BUNNY && lane == 0 && w_mlp_wave) {
+        atomicAdd(&P.counters->mlp_wave_evals, (unsigned long long)w_mlp_wave);
+        atomicAdd(&P.counters->mlp_lane_evals, (unsigned long long)w_mlp_lane);
+    }
     // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
     flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
                    lane == 0 ? w_hits : 0u, lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);

@@ -84,6 +84,8 @@ struct CamFrame {
 
 struct Counters {
     unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
+    // neural SDF (matrix-core path): MLP passes over a wave, and the ray-evaluations those passes were needed for
+    unsigned long long mlp_wave_evals, mlp_lane_evals;
 };
 
 struct Params {

@@ -163,6 +163,12 @@ class Renderer:
         self.api.call("get_counters", self._ctx, C.byref(c))
         return c
 
+    def counter(self, name: str) -> int:
+        """one named work counter of the last sample() call; beyond Counters: "mlp_wave_evals", "mlp_lane_evals"."""
+        v = C.c_uint64()
+        self.api.call("get_counter", self._ctx, name.encode(), C.byref(v))
+        return int(v.value)
+
     def last_sample_ms(self):
         a, b, n = C.c_float(), C.c_float(), C.c_int()
         self.api.call("last_sample_ms", self._ctx, C.byref(a), C.byref(b), C.byref(n))
