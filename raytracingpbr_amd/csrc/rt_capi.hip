@@ -598,10 +598,13 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     {
         const float rho = c->cfg.box_round;
         P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
-        P.box_two_rho = rho + rho;
+        // the squared-distance keys of nearest_boxes_lazy are carried scaled by 4 (exact): thresholds likewise
+        P.box_four_rho = 4.0f * rho;
         P.box_rho2m = (float)((double)rho * (double)rho * (1.0 + 1.0 / 524288.0));
         if (P.box_rho2m > 0.0f) P.box_rho2m = nextafterf(P.box_rho2m, INFINITY);
         P.box_4rho2m = nextafterf((float)(4.0 * (double)rho * (double)rho * (1.0 + 1.0 / 524288.0)), INFINITY);
+        P.box_rho2m *= 4.0f;
+        P.box_4rho2m *= 4.0f;
     }
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)

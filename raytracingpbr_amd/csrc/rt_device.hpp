@@ -154,6 +154,7 @@ RT_D void bunny_bias_stage(const float* __restrict__ w, float* bias_lds) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 RT_D f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#define RT_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 RT_D void bunny_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -161,6 +162,7 @@ RT_D void bunny_lds_fence() {
 }
 #else
 RT_D f4v mfma4(float, float, f4v c) { return c; }
+#define RT_SCHED_BARRIER()
 RT_D void bunny_lds_fence() {}
 #endif
 
@@ -175,42 +177,57 @@ RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, floa
     bunny_lds_fence();
     const f4v bias1 = *reinterpret_cast<const f4v*>(&bias_lds[4 * g]);
     const f4v bias2 = *reinterpret_cast<const f4v*>(&bias_lds[16 + 4 * g]);
+    // Software pipeline over the two ray blocks of a half: while block A's four dependent MFMAs of a layer are in
+    // flight (each waits ~36 cycles for the previous one's accumulator), block B's four sines of the previous layer
+    // issue on the VALU — one sine (11 instructions) per MFMA, pinned with scheduling barriers.  A wave then keeps
+    // both pipes busy by itself instead of alternating MFMA-only and VALU-only phases.
 #pragma nounroll
     for (int h = 0; h < 2; h++) {
-        f4v act[2];
-        // ---- input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b); lane group g supplies component g of ray io
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const float c = in[(g < 3 ? g : 0) * 64 + (2 * h + r) * 16 + io];
-            const float b = g < 3 ? c : 1.0f;
-            const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
-            const f4v d = mfma4(F.a0, b, z);
-#pragma unroll
-            for (int v = 0; v < 4; v++) act[r][v] = sin_pi_(d[v]);
+        const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
+        f4v act0, act1, c0, c1;
+        {   // input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b); lane group g supplies component g of ray io
+            const float x0 = in[(g < 3 ? g : 0) * 64 + (2 * h) * 16 + io];
+            const float x1 = in[(g < 3 ? g : 0) * 64 + (2 * h + 1) * 16 + io];
+            c0 = mfma4(F.a0, g < 3 ? x0 : 1.0f, z);
+            c1 = mfma4(F.a0, g < 3 ? x1 : 1.0f, z);
         }
-        // ---- two hidden layers: the result registers are the next B operands
+        RT_SCHED_BARRIER();
 #pragma unroll
-        for (int layer = 0; layer < 2; layer++) {
-            f4v c[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        for (int v = 0; v < 4; v++) act0[v] = sin_pi_(c0[v]);
+        RT_SCHED_BARRIER();
+        c0 = z;
 #pragma unroll
-            for (int kb = 0; kb < 4; kb++) {
-#pragma unroll
-                for (int r = 0; r < 2; r++) c[r] = mfma4(layer == 0 ? F.a1[kb] : F.a2[kb], act[r][kb], c[r]);
-            }
-            const f4v bias = layer == 0 ? bias1 : bias2;
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-#pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    float sn = sin_pi_(c[r][v] + bias[v]);
-                    if (layer == 1) sn = sn * INV_1_4;
-                    act[r][v] = sn + act[r][v];
-                }
-            }
+        for (int kb = 0; kb < 4; kb++) {          // layer 1 of block 0 || input sines of block 1
+            c0 = mfma4(F.a1[kb], act0[kb], c0);
+            act1[kb] = sin_pi_(c1[kb]);
+            RT_SCHED_BARRIER();
         }
+        c1 = z;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {          // layer 1 of block 1 || layer-1 sines of block 0
+            c1 = mfma4(F.a1[kb], act1[kb], c1);
+            act0[kb] = sin_pi_(c0[kb] + bias1[kb]) + act0[kb];
+            RT_SCHED_BARRIER();
+        }
+        c0 = z;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {          // layer 2 of block 0 || layer-1 sines of block 1
+            c0 = mfma4(F.a2[kb], act0[kb], c0);
+            act1[kb] = sin_pi_(c1[kb] + bias1[kb]) + act1[kb];
+            RT_SCHED_BARRIER();
+        }
+        c1 = z;
+#pragma unroll
+        for (int kb = 0; kb < 4; kb++) {          // layer 2 of block 1 || layer-2 sines of block 0
+            c1 = mfma4(F.a2[kb], act1[kb], c1);
+            act0[kb] = sin_pi_(c0[kb] + bias2[kb]) * INV_1_4 + act0[kb];
+            RT_SCHED_BARRIER();
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) act1[v] = sin_pi_(c1[v] + bias2[v]) * INV_1_4 + act1[v];
         // ---- back to lane = ray: [ray][neuron 4g .. 4g+3]
-#pragma unroll
-        for (int r = 0; r < 2; r++) *reinterpret_cast<f4v*>(&lds[((2 * h + r) * 16 + io) * 16 + 4 * g]) = act[r];
+        *reinterpret_cast<f4v*>(&lds[((2 * h) * 16 + io) * 16 + 4 * g]) = act0;
+        *reinterpret_cast<f4v*>(&lds[((2 * h + 1) * 16 + io) * 16 + 4 * g]) = act1;
     }
     bunny_lds_fence();
     CFloatPtr ow = (CFloatPtr)wg + 64 + 544;
@@ -386,23 +403,32 @@ RT_D ObjM load_obj(ObjTab) { return ObjM{}; }   // host pass only parses the dev
 // full expression for the wave (~1 % of the wave-steps).  Otherwise (idx, best) are bit-for-bit the
 // reference's: the winner's distance is computed with the same operations, |fl(sqrt_(s2) - rho)| or
 // fl(rho - mx).
+// (Measured dead end: a first tier that assumes "no marching lane is inside a box" and drops the core key saves 5 of
+// 27 instructions per box, but over-relaxed steps (omega = 1.6) land inside a box once per raycast on purpose, so half
+// of the wave-steps have such a lane and pay both tiers: 130 -> 177 ms.)
 template <int NOBJ, uint32_t SIG>
 RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
     const float rho = P.cfg.box_round;
-    const float two_rho = P.box_two_rho;
+    const float four_rho = P.box_four_rho;
     float k1 = 3.0e38f, k2 = 3.0e38f, k3 = 3.0e38f;   // the three smallest keys
     float pmx = 1.0f;                                  // max3(q) of the object with the smallest key (<= 0: core)
     bool has_core = false;
     idx = 0;
+    // All keys are carried SCALED BY 4 (exact): max(q,0) is formed as (q + |q|) = 2 max(q,0) — an add with an abs
+    // source modifier runs at the full FP32 rate on gfx950, v_max_f32 at half of it (tools/ubench/valu_rate.hip:
+    // fma/add/mul/sub on VGPRs 2.45 cycles per wave instruction; min/max/med3/cmp/cndmask/shifts and every
+    // instruction with an SGPR, DPP or SDWA operand 4.2) — and the core key as (2 (2 rho - mx))^2.  Scaling by a power
+    // of two commutes with every rounding here, so the order of the keys, the 2^-20 closeness band and the winner's
+    // distance (sqrt of the key / 4: same v_sqrt_f32 input, see sqrt_quarter_) are bit-for-bit what they were.
     auto visit = [&](const ObjM& o, int i, int cls) {
         vec3 l = to_local<KIND_BOXES>(P, o, p, cls);
         float qx = fabs_(l.x) - o.sx, qy = fabs_(l.y) - o.sy, qz = fabs_(l.z) - o.sz;
         float mx = fmax_(qx, fmax_(qy, qz));
-        vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
-        float s2 = dot(m, m);
-        float t = two_rho - mx;
+        vec3 u = mk(qx + fabs_(qx), qy + fabs_(qy), qz + fabs_(qz));
+        float s2 = dot(u, u);
+        float t = fma_(mx, -2.0f, four_rho);
         const bool out = mx > 0.0f;
         has_core = has_core || !out;
         float key = out ? s2 : t * t;
@@ -424,7 +450,7 @@ RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
     const bool suspect = k3 <= lim || (k2 <= lim && (k2 != k1 || has_core)) || (k1 < P.box_rho2m && k2 < P.box_4rho2m);
     if (__any(suspect)) return false;
     const bool core = !(pmx > 0.0f);
-    float d = core ? rho - pmx : fabs_(sqrt_(k1) - rho);
+    float d = core ? rho - pmx : fabs_(sqrt_quarter_(k1) - rho);
     if (P.cfg.nearest_init && !(d < P.cfg.max_dis)) {   // src/ form: the search starts from (0, MAX_DIS)
         d = P.cfg.max_dis;
         idx = 0;
@@ -441,8 +467,8 @@ RT_D void nearest(const Params& P, vec3 p, int& idx, float& best) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (KIND == KIND_BOXES && NOBJ > 0) {
         if (P.box_lazy && nearest_boxes_lazy<NOBJ, SIG>(P, p, idx, best)) return;
-#ifdef RT_DEBUG_LAZY
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)) == 0) atomicAdd(&P.counters->deposits, 1ull);
+#ifdef RT_DEBUG_LAZY   // wave-steps that fell back to the exact expression (read with rtpbr_get_counter "mlp_lane_evals")
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)) == 0) atomicAdd(&P.counters->mlp_lane_evals, 1ull);
 #endif
     }
 #endif

@@ -62,6 +62,22 @@ RT_HD float sqrt_(float x) {
     return __builtin_sqrtf(x);
 #endif
 }
+// sqrt_(x / 4) for an x that is an exact multiple-of-4 scaling: the same v_sqrt_f32 input (x/4 * 2^32 = x * 2^30)
+RT_HD float sqrt_quarter_(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float xs = x * 1073741824.0f;
+    float y = __builtin_amdgcn_sqrtf(xs);
+    float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    float rm = __builtin_fmaf(-ym, y, xs);
+    float rp = __builtin_fmaf(-yp, y, xs);
+    y = (0.0f >= rm) ? ym : y;
+    y = (0.0f < rp) ? yp : y;
+    return y * 1.52587890625e-05f;
+#else
+    return __builtin_sqrtf(x * 0.25f);
+#endif
+}
 RT_HD float sqrt_ieee_(float x) { return __builtin_sqrtf(x); }
 RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
 RT_HD vec3 normalize(vec3 a) {

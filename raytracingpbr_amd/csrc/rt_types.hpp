@@ -116,9 +116,9 @@ struct Params {
     int32_t cull_ok;        // host side: every shape is 1-Lipschitz and n_obj <= 8: primary_rays may cull (nearest_culled)
     float cull_extent;      // nearest_culled: scale of the rounding allowance
     int32_t box_lazy;       // nearest_boxes_lazy enabled (option lazy_sqrt, box_round >= 0)
-    float box_two_rho;      // 2 * box_round
-    float box_rho2m;        // box_round^2 * (1 + 2^-19): a smaller key means an object is in its rounding shell
-    float box_4rho2m;       // (2 box_round)^2 * (1 + 2^-19): a larger key means that object is farther than box_round
+    float box_four_rho;     // 4 * box_round (keys are carried scaled by 4, see nearest_boxes_lazy)
+    float box_rho2m;        // 4 * box_round^2 * (1 + 2^-19): a smaller key means an object is in its rounding shell
+    float box_4rho2m;       // 4 * (2 box_round)^2 * (1 + 2^-19): a larger key means that object is farther than box_round
     float4* image_buffer;   // T7 (W,H) float4
     float* image_pixels;    // T8 (W,H,3)
     rtpbr_ray* ray_buffer;  // T6
