@@ -293,6 +293,20 @@ int rtpbr_packed_bytes(rtpbr_ctx* ctx, size_t* nbytes);
 int rtpbr_pack_tiles(rtpbr_ctx* ctx, void* device_dst);
 int rtpbr_unpack_tiles(rtpbr_ctx* ctx, const void* device_src, int src_rank);
 
+/* ---- the ONE collective of the multi-GPU path, on RCCL directly (rt_rccl.hip).
+ * Replaces nothing in the reference (it is single-device); completes rtpbr_set_tiles / pack / unpack
+ * so that hosts without PyTorch can render on N GPUs: every rank packs its tiles, one ncclGather (rccl.h:745) moves
+ * them to rank 0, rank 0 scatters them into its full image_buffer (T7) — all enqueued on the context's stream.
+ * One process per GPU: rank 0 obtains a 128-byte id, ships it to the other ranks by the host's own means, every rank
+ * calls rtpbr_rccl_init (collective, like ncclCommInitRank, rccl.h:220), then rtpbr_gather_tiles (collective).
+ * One process driving G contexts: rtpbr_rccl_init_all (ncclCommInitAll, rccl.h:236) and rtpbr_gather_tiles_all.
+ * rank/world must equal the ones given to rtpbr_set_tiles.  librccl is dlopen-ed at the first of these calls. */
+int rtpbr_rccl_unique_id(void* out, size_t nbytes);                       /* nbytes >= 128 */
+int rtpbr_rccl_init(rtpbr_ctx* ctx, const void* unique_id, size_t nbytes, int rank, int world);
+int rtpbr_rccl_init_all(rtpbr_ctx** ctxs, int n);
+int rtpbr_gather_tiles(rtpbr_ctx* ctx);
+int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n);
+
 /* Measurement hooks (SURVEY.md §5 tracing row, §8(d)). */
 int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking */
 /* One counter by name: the six above, plus "mlp_wave_evals" / "mlp_lane_evals" — passes of the wave-cooperative

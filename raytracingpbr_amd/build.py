@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librtpbr_hip.so")
-SOURCES = ["rt_kernels.hip", "rt_capi.hip"]
-HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", os.path.join("..", "..", "include", "rtpbr.h")]
+SOURCES = ["rt_kernels.hip", "rt_capi.hip", "rt_rccl.hip"]
+HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", "rt_ctx.hpp", os.path.join("..", "..", "include", "rtpbr.h")]
 # -ffp-contract=off: only the fmaf written in rt_math.hpp are fused (bit-reproducible results);
 # no -ffast-math: f32 divide and sqrt stay correctly rounded.
 # -fno-slp-vectorize: the SLP vectoriser pairs independent f32 ops of neighbouring boxes into
@@ -19,7 +19,7 @@ HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", os.path.join("..", ".
 # moves: measured +6 % on the headline kernel without them (122 -> 113 VGPRs).
 # -amdgpu-use-amdgpu-trackers: the scheduler tracks register pressure with the GCN trackers: +1.7 %.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-fPIC", "-shared", "-Wno-unused-value"]
+         "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-fPIC", "-shared", "-Wno-unused-value", "-ldl"]
 
 
 def hipcc():

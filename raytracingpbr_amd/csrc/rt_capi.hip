@@ -12,93 +12,21 @@
 #include <cstring>
 #include <vector>
 
-#include "rt_device.hpp"
-
-namespace rt {
-void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
-void launch_accumulate(const Params& P, hipStream_t st);
-void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
-void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
-int persistent_pool_blocks_per_cu(int kind);
-void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st);
-void launch_post_process(const Params& P, hipStream_t st);
-void launch_pack(const Params& P, float4* dst, hipStream_t st);
-void launch_unpack(const Params& P, const float4* src, hipStream_t st);
-void launch_math_probe(int op, const float* a, const float* b, float* out, float* out2, int n, hipStream_t st);
-int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
-void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
-void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
-}  // namespace rt
+#include "rt_ctx.hpp"
 
 using namespace rt;
 
 static thread_local char g_err[512];
-static int fail(int code, const char* fmt, const char* a = "") {
+int rt_fail(int code, const char* fmt, const char* a) {
     snprintf(g_err, sizeof g_err, fmt, a);
     return code;
 }
-#define HIP_TRY(expr)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (expr);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-            return RTPBR_EHIP;                                                         \
-        }                                                                              \
-    } while (0)
-
-struct rtpbr_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool have_cfg = false, have_scene = false, have_cam = false;
-    rtpbr_config cfg{};
-    rtpbr_object obj[MAX_OBJ];
-    int n_obj = 0;
-    int kind = KIND_GENERIC;
-    rtpbr_camera cam{};
-    Params P{};
-    // device buffers
-    float4* image_buffer = nullptr;
-    float* image_pixels = nullptr;
-    rtpbr_ray* ray_buffer = nullptr;
-    float2* diff_buffer = nullptr;
-    float* diff_pixels = nullptr;
-    ObjFull* objfull = nullptr;
-    float4* env = nullptr;
-    float* bunny = nullptr;
-    float4* stage = nullptr;
-    size_t stage_cap = 0;  // bytes
-    float2* primary = nullptr;
-    size_t primary_cap = 0;
-    int primary_split = 1;
-    int specialize = 1;      // use the RT_BOX_SIGNATURES instance the scene fits
-    int lazy_sqrt = 1;       // all-box scenes: nearest box on squared distances (nearest_boxes_lazy)
-    uint32_t scene_sig = 0;
-    ObjM objm[MAX_OBJ];      // march table in its general layout; P.objm is filled per launch (pack_objects)
-    unsigned int* work_counter = nullptr;
-    Counters* counters = nullptr;
-    // tiles
-    int tile_w = 0, tile_h = 0, rank = 0, world = 1;
-    // progress
-    uint32_t sample_base = 0;
-    unsigned long long deposits_host = 0;
-    // options
-    long long staging_bytes = 16LL << 30;  // 288 GB of HBM: a whole 1080p x 256 spp step (8.5 GB of samples + 4.2 GB of primary records) is one launch
-    int wait_lanes = 24;
-    int shade_lanes = 56;
-    int swap_lanes = 8;
-    int mlp_lanes = 16;
-    int mlp_mfma = 1;
-    int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
-    int waves_per_cu = 0;  // 0 = from the occupancy query
-    // timing
-    std::vector<hipEvent_t> ev;
-    int ev_used = 0;
-    std::vector<hipEvent_t> evp;   // pairs around the primary_rays launches
-    int evp_used = 0;
-    hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
-    bool timed = false;
-    int n_cu = 256;
-};
+int rt_fail_hip(const char* expr, hipError_t e) {
+    snprintf(g_err, sizeof g_err, "%s failed: %s", expr, hipGetErrorString(e));
+    return RTPBR_EHIP;
+}
+static int fail(int code, const char* fmt, const char* a = "") { return rt_fail(code, fmt, a); }
+#define HIP_TRY(expr) RT_HIP_TRY(expr)
 
 static int set_dev(rtpbr_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
@@ -154,6 +82,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->bunny);
     (void)hipFree(c->stage);
     (void)hipFree(c->primary);
+    rt_rccl_release(c);
     (void)hipFree(c->work_counter);
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);

@@ -1,0 +1,199 @@
+// rt_rccl.hip — the ONE collective of the multi-GPU path, on RCCL directly.
+//
+// The frame is tile-partitioned (rtpbr_set_tiles); each rank renders its tiles into its own image_buffer (T7).  At
+// the end of a render (or at a progressive checkpoint) every rank packs its tiles tile-major into one contiguous
+// buffer and ONE ncclGather (rccl.h:745, an RCCL extension: per-rank point-to-point over xGMI, no ring) moves
+// P/G x 16 B per rank to rank 0, which scatters the buffers back into the full frame.  Pack, gather and unpack are
+// enqueued on the context's own HIP stream: no host synchronisation inside.  The reference has no multi-device
+// path; these entry points let ANY host (C, Go/cgo, Java/JNI ...) do N > 1 without PyTorch:
+//   one process per GPU   : rank 0 calls rtpbr_rccl_unique_id, ships the 128 bytes to the others by its own means
+//                           (MPI, a file, torch.distributed), every rank calls rtpbr_rccl_init, later
+//                           rtpbr_gather_tiles;
+//   one process, G devices: rtpbr_rccl_init_all(ctxs, G) then rtpbr_gather_tiles_all(ctxs, G) (ncclCommInitAll,
+//                           rccl.h:236, and a ncclGroupStart/End around the G gathers).
+// librccl is loaded with dlopen at first use, so the library has no link-time dependency on it and single-GPU
+// hosts never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "rt_ctx.hpp"
+
+using namespace rt;
+
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGather) Gather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return RTPBR_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return rt_fail(RTPBR_EHIP, "cannot load librccl: %s", dlerror());
+#define RT_SYM(field, name)                                                      \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));     \
+    if (!g_rccl.field) return rt_fail(RTPBR_EHIP, "librccl lacks %s", name)
+    RT_SYM(GetUniqueId, "ncclGetUniqueId");
+    RT_SYM(CommInitRank, "ncclCommInitRank");
+    RT_SYM(CommInitAll, "ncclCommInitAll");
+    RT_SYM(CommDestroy, "ncclCommDestroy");
+    RT_SYM(Gather, "ncclGather");
+    RT_SYM(GroupStart, "ncclGroupStart");
+    RT_SYM(GroupEnd, "ncclGroupEnd");
+    RT_SYM(GetErrorString, "ncclGetErrorString");
+    RT_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
+#undef RT_SYM
+    g_rccl.h = h;
+    return RTPBR_OK;
+}
+}  // namespace
+
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) return rt_fail(RTPBR_EHIP, #expr " failed: %s", g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+extern "C" int rtpbr_rccl_unique_id(void* out, size_t nbytes) {
+    if (!out || nbytes < NCCL_UNIQUE_ID_BYTES) return rt_fail(RTPBR_EINVAL, "need a %s-byte buffer", "128");
+    if (int r = load_rccl()) return r;
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(out, &id, NCCL_UNIQUE_ID_BYTES);
+    return RTPBR_OK;
+}
+
+// Buffers of one rank: its packed tiles, and on rank 0 room for every rank's.
+static int ensure_gather_buffers(rtpbr_ctx* c) {
+    const size_t bytes = (size_t)c->P.np * sizeof(float4);
+    if (bytes > c->gather_cap || (c->rank == 0) != (c->gather_recv != nullptr)) {
+        RT_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->gather_send);
+        (void)hipFree(c->gather_recv);
+        c->gather_send = c->gather_recv = nullptr;
+        c->gather_cap = 0;
+        RT_HIP_TRY(hipMalloc(&c->gather_send, bytes));
+        if (c->rank == 0) RT_HIP_TRY(hipMalloc(&c->gather_recv, bytes * (size_t)c->world));
+        c->gather_cap = bytes;
+    }
+    return RTPBR_OK;
+}
+
+static int check_comm(rtpbr_ctx* c) {
+    if (!c || !c->have_cfg) return rt_fail(RTPBR_ESTATE, "set_config first");
+    if (!c->comm) return rt_fail(RTPBR_ESTATE, "rtpbr_rccl_init first");
+    if (c->comm_world != c->world || c->comm_rank != c->rank)
+        return rt_fail(RTPBR_ESTATE, "rtpbr_set_tiles rank/world differ from the communicator's");
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_rccl_init(rtpbr_ctx* c, const void* unique_id, size_t nbytes, int rank, int world) {
+    if (!c || !unique_id || nbytes < NCCL_UNIQUE_ID_BYTES) return rt_fail(RTPBR_EINVAL, "bad rccl_init arguments");
+    if (world < 1 || rank < 0 || rank >= world) return rt_fail(RTPBR_EINVAL, "bad rank/world");
+    if (int r = load_rccl()) return r;
+    RT_HIP_TRY(hipSetDevice(c->device));
+    if (c->comm) {
+        (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm;
+    NCCL_TRY(g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_rccl_init_all(rtpbr_ctx** ctxs, int n) {
+    if (!ctxs || n < 1 || n > 64) return rt_fail(RTPBR_EINVAL, "bad rccl_init_all arguments");
+    if (int r = load_rccl()) return r;
+    int devs[64];
+    ncclComm_t comms[64];
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return rt_fail(RTPBR_EINVAL, "null ctx");
+        devs[i] = ctxs[i]->device;
+    }
+    NCCL_TRY(g_rccl.CommInitAll(comms, n, devs));
+    for (int i = 0; i < n; i++) {
+        if (ctxs[i]->comm) (void)g_rccl.CommDestroy((ncclComm_t)ctxs[i]->comm);
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_world = n;
+    }
+    return RTPBR_OK;
+}
+
+// pack -> ncclGather -> (root) unpack, all on the context's stream
+static int enqueue_gather(rtpbr_ctx* c) {
+    RT_HIP_TRY(hipSetDevice(c->device));
+    if (int r = ensure_gather_buffers(c)) return r;
+    c->P.cfg = c->cfg;
+    c->P.image_buffer = c->image_buffer;
+    launch_pack(c->P, (float4*)c->gather_send, c->stream);
+    RT_HIP_TRY(hipGetLastError());
+    NCCL_TRY(g_rccl.Gather(c->gather_send, c->gather_recv, (size_t)c->P.np * 4, ncclFloat, 0, (ncclComm_t)c->comm, c->stream));
+    return RTPBR_OK;
+}
+static int enqueue_unpack(rtpbr_ctx* c) {
+    if (c->rank != 0) return RTPBR_OK;
+    RT_HIP_TRY(hipSetDevice(c->device));
+    for (int src = 1; src < c->world; src++) {       // rank 0's own tiles are already in place
+        Params P = c->P;
+        P.cfg = c->cfg;
+        P.image_buffer = c->image_buffer;
+        P.rank = src;
+        launch_unpack(P, (const float4*)c->gather_recv + (size_t)src * (size_t)c->P.np, c->stream);
+    }
+    RT_HIP_TRY(hipGetLastError());
+    ncclResult_t async = ncclSuccess;
+    NCCL_TRY(g_rccl.CommGetAsyncError((ncclComm_t)c->comm, &async));
+    if (async != ncclSuccess) return rt_fail(RTPBR_EHIP, "RCCL asynchronous error: %s", g_rccl.GetErrorString(async));
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_gather_tiles(rtpbr_ctx* c) {
+    if (int r = check_comm(c)) return r;
+    if (int r = enqueue_gather(c)) return r;
+    return enqueue_unpack(c);
+}
+
+extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
+    if (!ctxs || n < 1) return rt_fail(RTPBR_EINVAL, "bad gather_tiles_all arguments");
+    for (int i = 0; i < n; i++)
+        if (int r = check_comm(ctxs[i])) return r;
+    NCCL_TRY(g_rccl.GroupStart());
+    int rc = RTPBR_OK;
+    for (int i = 0; i < n && rc == RTPBR_OK; i++) rc = enqueue_gather(ctxs[i]);
+    NCCL_TRY(g_rccl.GroupEnd());
+    if (rc != RTPBR_OK) return rc;
+    for (int i = 0; i < n; i++)
+        if (int r = enqueue_unpack(ctxs[i])) return r;
+    return RTPBR_OK;
+}
+
+// called by rtpbr_destroy
+void rt_rccl_release(rtpbr_ctx* c) {
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+    (void)hipFree(c->gather_send);
+    (void)hipFree(c->gather_recv);
+    c->gather_send = c->gather_recv = nullptr;
+}

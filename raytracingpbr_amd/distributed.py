@@ -58,6 +58,20 @@ class TileGather:
             self.r.image_buffer = full
 
 
+def rccl_group(renderers):
+    """One process driving G devices: ncclCommInitAll over the renderers' devices (rank i = renderers[i]); afterwards
+    gather_group(renderers) runs the single gather.  Tiles must have been set with rank i of len(renderers)."""
+    import ctypes as C
+    arr = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
+    renderers[0].api.call("rccl_init_all", arr, len(renderers))
+
+
+def gather_group(renderers):
+    import ctypes as C
+    arr = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
+    renderers[0].api.call("gather_tiles_all", arr, len(renderers))
+
+
 def render_distributed(renderer, spp, rank, world, tile=None, device=None, refresh=True):
     """refresh -> spp samples on this rank's tiles -> one gather -> (rank 0) post_process."""
     tg = TileGather(renderer, rank, world, tile, device)

@@ -192,6 +192,20 @@ class Renderer:
     def unpack_tiles(self, device_ptr: int, src_rank: int):
         self.api.call("unpack_tiles", self._ctx, C.c_void_p(device_ptr), int(src_rank))
 
+    # RCCL directly, without torch.distributed (include/rtpbr.h "the ONE collective")
+    def rccl_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.api.call("rccl_unique_id", buf, 128)
+        return buf.raw
+
+    def rccl_init(self, unique_id: bytes, rank: int, world: int):
+        """collective over all ranks (ncclCommInitRank); rank/world as given to set_tiles"""
+        self.api.call("rccl_init", self._ctx, C.c_char_p(unique_id), len(unique_id), int(rank), int(world))
+
+    def gather_tiles(self):
+        """collective: pack -> one ncclGather to rank 0 -> rank 0 unpacks, on this context's stream"""
+        self.api.call("gather_tiles", self._ctx)
+
     def stream(self) -> int:
         s = C.c_void_p()
         self.api.call("get_stream", self._ctx, C.byref(s))

@@ -453,3 +453,39 @@ def test_edge_cases_match_oracle():
     assert np.array_equal(bits(merged), bits(full.image_buffer))
     with pytest.raises(RtpbrError):
         g.set_scene(Scene(objs + objs[:1], False, sc.camera))          # 33 objects > RTPBR_MAX_OBJECTS
+
+
+def test_rccl_gather_through_the_c_abi():
+    """The ONE collective on RCCL directly (include/rtpbr.h: rtpbr_rccl_* / rtpbr_gather_tiles), no torch.distributed.
+    One GPU here, so the communicators have one rank each: ncclCommInitRank + ncclGather to self run for real (library
+    load, communicator, stream-ordered pack -> gather -> unpack), and both host styles are exercised: one process per GPU
+    (unique id + init) and one process driving its contexts (init_all + grouped gather)."""
+    from raytracingpbr_amd.distributed import gather_group, rccl_group
+    case = case_by_name("cornell_v3_8b_wide")
+    ref = Renderer(case.scene, case.cfg)
+    ref.sample(5)
+    want = ref.image_buffer
+    r = Renderer(case.scene, case.cfg)
+    r.set_tiles(16, 16, 0, 1)
+    uid = r.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    r.rccl_init(uid, 0, 1)
+    r.sample(5)
+    r.gather_tiles()
+    r.sync()
+    assert np.array_equal(bits(r.image_buffer), bits(want))
+    # rank/world of the communicator must match the tile partition
+    r.set_tiles(16, 16, 0, 2)
+    with pytest.raises(RtpbrError):
+        r.gather_tiles()
+    # no communicator yet -> a clear error
+    f = Renderer(case.scene, case.cfg)
+    with pytest.raises(RtpbrError):
+        f.gather_tiles()
+    g = Renderer(case.scene, case.cfg)
+    g.set_tiles(16, 16, 0, 1)
+    rccl_group([g])
+    g.sample(5)
+    gather_group([g])
+    g.sync()
+    assert np.array_equal(bits(g.image_buffer), bits(want))
