@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "rt_ctx.hpp"
@@ -41,10 +42,13 @@ Rccl g_rccl;
 
 int load_rccl() {
     if (g_rccl.h) return RTPBR_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // ROCm's own librccl first (a PyTorch wheel bundles its own copy under the same soname, and a process that has
+    // imported torch would otherwise get that one: measured 7 minutes of communicator set-up against 2.6 s);
+    // RTPBR_RCCL_LIB overrides.  RTLD_LOCAL: two copies of RCCL in one process must not see each other's symbols.
+    const char* names[] = {getenv("RTPBR_RCCL_LIB"), "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     void* h = nullptr;
     for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) return rt_fail(RTPBR_EHIP, "cannot load librccl: %s", dlerror());
 #define RT_SYM(field, name)                                                      \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));     \

@@ -23,6 +23,12 @@ def build_oracle():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
 
+def use_library(path):
+    """bench.py's cpu_baseline leg times the -O3 -march=native build of the same source"""
+    global _api, ORACLE_LIB
+    ORACLE_LIB, _api = path, None
+
+
 def oracle_api():
     global _api
     if _api is None:
