@@ -471,7 +471,8 @@ static int next_event_of(std::vector<hipEvent_t>& pool, int& used, hipEvent_t* o
     if (int r_ = next_event_of(pool, used, &var)) return r_
 
 static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
-    int per_cu = trace_blocks_per_cu(c->kind, c->n_obj, c->P.box_sig, c->scheduler < 0 ? 1 : c->scheduler);
+    int per_cu = c->jit_mod ? c->jit_mod->trace_blocks_per_cu
+                            : trace_blocks_per_cu(c->kind, c->n_obj, c->P.box_sig, c->scheduler < 0 ? 1 : c->scheduler);
     if (per_cu <= 0) per_cu = 2;
     if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
     long long grid = (long long)per_cu * c->n_cu;
@@ -508,7 +509,6 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && c->cfg.max_raytrace > 2047) P.scheduler = 0;
     // signature instances exist for the complete-path kernels only
     P.box_sig = (c->specialize && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH) ? c->scene_sig : 0;
-    pack_objects(c, P);
     {
         // nearest_culled needs |sdf| to be 1-Lipschitz: true for every analytic shape except a cone whose
         // slope vector (scale.x, scale.z) is longer than 1; the rounding allowance scales with the scene
@@ -524,6 +524,32 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.cull_ok = ok ? 1 : 0;
         P.cull_extent = 4.0f * ext;
     }
+    // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
+    c->jit_mod = nullptr;
+    if (c->jit != 0 && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && P.scheduler == 1 && c->n_obj <= 8 &&
+        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC)) {
+        const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
+        if (c->jit == 1 || !aot_special) {
+            RtJitKey key{};
+            key.kind = c->kind;
+            key.n_obj = c->n_obj;
+            for (int i = 0; i < c->n_obj; i++) {
+                key.types |= (unsigned long long)(c->objm[i].type + 1) << (4 * i);
+                key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
+            }
+            key.cull = P.cull_ok;
+            key.waves = c->kind == KIND_BOXES ? 6 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
+            RtJitModule* jm = nullptr;
+            const int r = rt_jit_acquire(c, key, &jm);
+            if (r == RTPBR_OK) {
+                c->jit_mod = jm;
+                P.box_sig = key.sig;
+            } else if (c->jit == 1) {
+                return r;
+            }
+        }
+    }
+    pack_objects(c, P);
     {
         const float rho = c->cfg.box_round;
         P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
@@ -613,13 +639,20 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 NEXT_EVENT(c->evp, c->evp_used, pa);
                 NEXT_EVENT(c->evp, c->evp_used, pb);
                 HIP_TRY(hipEventRecord(pa, c->stream));
-                launch_primary(P, c->kind, c->n_cu, c->stream);
+                if (c->jit_mod) {
+                    long long need = ((long long)P.total_items + 255) / 256, pg = (long long)c->n_cu * 8;
+                    if (int r = rt_jit_launch(c->jit_mod->primary, P, (unsigned)(pg < need ? pg : need), c->stream)) return r;
+                } else
+                    launch_primary(P, c->kind, c->n_cu, c->stream);
                 HIP_TRY(hipEventRecord(pb, c->stream));
             }
             NEXT_EVENT(c->ev, c->ev_used, a);
             NEXT_EVENT(c->ev, c->ev_used, b);
             HIP_TRY(hipEventRecord(a, c->stream));
-            launch_trace(P, c->kind, grid, c->stream);
+            if (c->jit_mod) {
+                if (int r = rt_jit_launch(c->jit_mod->trace, P, (unsigned)grid, c->stream)) return r;
+            } else
+                launch_trace(P, c->kind, grid, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
             launch_accumulate(P, c->stream);
             c->sample_base += (uint32_t)K;
@@ -758,6 +791,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     else if (!strcmp(name, "deposits")) *out = h.deposits + c->deposits_host;
     else if (!strcmp(name, "mlp_wave_evals")) *out = h.mlp_wave_evals;
     else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
+    else if (!strcmp(name, "jit_active")) *out = c->jit_mod ? 1 : 0;      // the last sample() ran a run-time compiled instance
     else return fail(RTPBR_EINVAL, "unknown counter %s", name);
     return RTPBR_OK;
 }
@@ -820,6 +854,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "lazy_sqrt")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "lazy_sqrt must be 0 or 1");
         c->lazy_sqrt = (int)value;
+    } else if (!strcmp(key, "jit")) {
+        if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "jit must be -1 (when no ahead-of-time specialisation fits), 0 (never) or 1 (always)");
+        c->jit = (int)value;
     } else if (!strcmp(key, "specialize")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "specialize must be 0 or 1");
         c->specialize = (int)value;

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
 #include <vector>
 
 #include "rt_device.hpp"
@@ -24,6 +25,24 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 }  // namespace rt
+
+// run-time compiled per-scene instances (rt_jit.hip)
+struct RtJitKey {
+    int kind, n_obj;
+    unsigned long long types;   // (shape type + 1) in 4 bits per object
+    unsigned sig;               // rotation class in 3 bits per object
+    int cull, waves;
+};
+struct RtJitModule {
+    hipModule_t module = nullptr;
+    hipFunction_t trace = nullptr, primary = nullptr;
+    int trace_blocks_per_cu = 0;
+    std::string path;
+};
+struct rtpbr_ctx;
+int rt_jit_build(const RtJitKey& key, std::string* out);
+int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out);
+int rt_jit_launch(hipFunction_t f, const rt::Params& P, unsigned grid, hipStream_t st);
 
 // error channel: thread-local message behind rtpbr_last_error() (defined in rt_capi.hip)
 int rt_fail(int code, const char* fmt, const char* a = "");
@@ -91,6 +110,11 @@ struct rtpbr_ctx {
     hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
     bool timed = false;
     int n_cu = 256;
+    // run-time compiled instance of the current scene (rt_jit.hip): -1 = when no ahead-of-time specialisation serves
+    // the scene, 0 = never, 1 = always (an error if it cannot be built)
+    int jit = -1;
+    RtJitModule* jit_mod = nullptr;   // the one the last rtpbr_sample() used (nullptr = ahead-of-time instance)
+    unsigned jit_sig = 0;
     // multi-GPU gather (rt_rccl.hip): communicator handle (ncclComm_t) and the packed-tile buffers
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;

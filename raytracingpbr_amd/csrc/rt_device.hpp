@@ -289,8 +289,8 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
 template <int KIND, typename OBJ>
 RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL) {
     vec3 d = p - mk(o.px, o.py, o.pz);
-    if constexpr (KIND == KIND_BOXES) {
-        // Sparse rotations.  `cls` is a COMPILE-TIME constant after unrolling (rotation signature of
+    if constexpr (KIND == KIND_BOXES || KIND == KIND_GENERIC) {
+        // Sparse rotations (every analytic shape: sphere / cylinder / cone see squares or |l|, a plane l.y - h).  `cls` is a COMPILE-TIME constant after unrolling (rotation signature of
         // the scene, see nearest); matrices whose off-axis entries are EXACTLY 0 and whose axis
         // entry is EXACTLY 1 (rotation about one coordinate axis, or none) are classified by
         // rtpbr_set_scene.  Dropping the x*0 and x*1 terms of the fma chain is exact for finite
@@ -310,9 +310,10 @@ RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL)
     return l;
 }
 
+// type_known >= 0: the shape type is a compile-time constant of the unrolled object loop (run-time compiled instances)
 template <int KIND, typename OBJ>
-RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL) {
-    return sdf_local<KIND>(P, o.type, to_local<KIND>(P, o, p, cls), o.sx, o.sy, o.sz);
+RT_D float signed_distance(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL, int type_known = -1) {
+    return sdf_local<KIND>(P, type_known >= 0 ? type_known : o.type, to_local<KIND>(P, o, p, cls), o.sx, o.sy, o.sz);
 }
 
 // ---------------------------------------------------------------- F8 nearest
@@ -487,7 +488,7 @@ RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best) {
         start = 0;
     } else {
         const ObjM o = load_obj<SIG, 0>(tab);
-        best = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(0)));
+        best = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(0), jit_type(0)));
         start = 1;
     }
     if constexpr (NOBJ > 0) {
@@ -498,13 +499,13 @@ RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best) {
             const ObjM oa = load_obj<SIG, i>(tab);
             const ObjM ob = load_obj<SIG, (i + 1 < NOBJ ? i + 1 : i)>(tab);
             if (i >= start) {
-                float d = fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i)));
+                float d = fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i), jit_type(i)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i : idx;
             }
             if constexpr (i + 1 < NOBJ) {
-                float d = fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1)));
+                float d = fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1), jit_type(i + 1)));
                 bool lt = d < best;
                 best = lt ? d : best;
                 idx = lt ? i + 1 : idx;
@@ -554,7 +555,7 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
         }
         if (__all(!active || lb[i] > bound)) return;              // provably not the nearest for any lane
         const ObjM o = load_obj<SIG, i>(tab);
-        float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i)));
+        float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i), jit_type(i)));
         lb[i] = d - eps;
         bool take = first || d < best;                            // nearest_init = 0: the first visited object initialises
         best = take ? d : best;

@@ -1,0 +1,196 @@
+// rt_jit.hip — per-scene instances compiled at run time (the generalisation of RT_BOX_SIGNATURES).
+//
+// The reference gets its specialisation from Taichi's JIT: `ti.static(range(len(OBJECTS)))` unrolls the object loop and
+// picks each object's shape function at compile time (src/scene.py:44-56).  Here the ahead-of-time library carries
+// general instances plus one listed rotation signature; for any OTHER scene of <= 8 analytic shapes the complete-path
+// kernels are compiled on demand by `hipcc --genco` from the same sources (rt_jit_tu.hip: object count, shape types,
+// rotation classes and the culling decision as compile-time constants; ~2 s), cached as a code object under
+// $RTPBR_JIT_CACHE / $XDG_CACHE_HOME/rtpbr / ~/.cache/rtpbr keyed by those constants and a hash of the sources, loaded
+// with hipModuleLoadData and launched with hipModuleLaunchKernel.  Results are bit-identical to the ahead-of-time
+// instances (same arithmetic).  If hipcc or the sources are not available the library silently keeps using the
+// ahead-of-time instance (option "jit" = 1 turns that into an error, 0 disables run-time compilation).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rt_ctx.hpp"
+
+using namespace rt;
+
+namespace {
+std::mutex g_mu;
+std::map<std::string, RtJitModule*> g_modules;   // process-wide: contexts on the same device share code objects
+
+std::string lib_dir() {
+    Dl_info info;
+    if (!dladdr((void*)&rt_jit_acquire, &info) || !info.dli_fname) return ".";
+    std::string p = info.dli_fname;
+    size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    bool ok = n >= 0 && fread(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+
+// FNV-1a over the sources the translation unit is made of: a changed source invalidates the cache
+bool source_hash(const std::string& dir, uint64_t* h) {
+    const char* files[] = {"rt_jit_tu.hip", "rt_trace.hpp", "rt_device.hpp", "rt_types.hpp", "rt_math.hpp", "../../include/rtpbr.h"};
+    uint64_t x = 1469598103934665603ull;
+    std::vector<char> buf;
+    for (const char* f : files) {
+        if (!read_file(dir + "/" + f, buf)) return false;
+        for (char c : buf) x = (x ^ (unsigned char)c) * 1099511628211ull;
+    }
+    *h = x;
+    return true;
+}
+
+std::string cache_dir() {
+    if (const char* e = getenv("RTPBR_JIT_CACHE")) return e;
+    if (const char* e = getenv("XDG_CACHE_HOME")) return std::string(e) + "/rtpbr";
+    if (const char* e = getenv("HOME")) return std::string(e) + "/.cache/rtpbr";
+    return "/tmp/rtpbr-cache";
+}
+
+void mkdirs(const std::string& d) {
+    for (size_t i = 1; i <= d.size(); i++)
+        if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0755);
+}
+
+std::string hipcc_path() {
+    if (const char* e = getenv("HIPCC")) return e;
+    if (access("/opt/rocm/bin/hipcc", X_OK) == 0) return "/opt/rocm/bin/hipcc";
+    return "hipcc";
+}
+
+// fork/exec, no shell: the arguments are ours, but paths come from the environment
+int run(const std::vector<std::string>& argv, const std::string& log) {
+    pid_t pid = fork();
+    if (pid < 0) return -1;
+    if (pid == 0) {
+        FILE* f = fopen(log.c_str(), "w");
+        if (f) {
+            dup2(fileno(f), 1);
+            dup2(fileno(f), 2);
+        }
+        std::vector<char*> a;
+        for (const std::string& s : argv) a.push_back(const_cast<char*>(s.c_str()));
+        a.push_back(nullptr);
+        execvp(a[0], a.data());
+        _exit(127);
+    }
+    int st = 0;
+    if (waitpid(pid, &st, 0) < 0) return -1;
+    return WIFEXITED(st) ? WEXITSTATUS(st) : -1;
+}
+}  // namespace
+
+// Compile (or fetch from the cache) the code object of `key`; path of the .hsaco in *out.  Needs no device.
+int rt_jit_build(const RtJitKey& key, std::string* out) {
+    const std::string dir = lib_dir();
+    uint64_t sh = 0;
+    if (!source_hash(dir, &sh)) return rt_fail(RTPBR_ESTATE, "run-time compilation: kernel sources not found next to the library (%s)", dir.c_str());
+    char name[256];
+    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig, key.cull,
+             key.waves, (unsigned long long)sh);
+    const std::string cdir = cache_dir();
+    const std::string path = cdir + "/" + name + ".hsaco";
+    if (access(path.c_str(), R_OK) == 0) {
+        *out = path;
+        return RTPBR_OK;
+    }
+    mkdirs(cdir);
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
+    const std::string tpath = path + tmp, log = path + ".log";
+    char d[6][64];
+    snprintf(d[0], 64, "-DRT_JIT_KIND=%d", key.kind);
+    snprintf(d[1], 64, "-DRT_JIT_NOBJ=%d", key.n_obj);
+    snprintf(d[2], 64, "-DRT_JIT_TYPES=0x%llxull", (unsigned long long)key.types);
+    snprintf(d[3], 64, "-DRT_JIT_SIG=0x%xu", key.sig);
+    snprintf(d[4], 64, "-DRT_JIT_CULL=%d", key.cull);
+    snprintf(d[5], 64, "-DRT_JIT_WAVES=%d", key.waves);
+    // the flags of raytracingpbr_amd/build.py: same code generation as the ahead-of-time library
+    std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
+                                     "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-unused-value",
+                                     d[0], d[1], d[2], d[3], d[4], d[5], dir + "/rt_jit_tu.hip", "-o", tpath};
+    const int rc = run(argv, log);
+    if (rc != 0 || access(tpath.c_str(), R_OK) != 0) {
+        unlink(tpath.c_str());
+        return rt_fail(RTPBR_ESTATE, "run-time compilation failed (hipcc log: %s)", log.c_str());
+    }
+    if (rename(tpath.c_str(), path.c_str()) != 0) {
+        unlink(tpath.c_str());
+        return rt_fail(RTPBR_ESTATE, "cannot move the compiled code object into the cache (%s)", path.c_str());
+    }
+    unlink(log.c_str());
+    *out = path;
+    return RTPBR_OK;
+}
+
+int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
+    char id[192];
+    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig, key.cull,
+             key.waves);
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_modules.find(id);
+    if (it != g_modules.end()) {
+        *out = it->second;
+        return it->second ? RTPBR_OK : rt_fail(RTPBR_ESTATE, "run-time compilation failed earlier for this scene");
+    }
+    g_modules[id] = nullptr;                         // a failure is remembered: no recompilation storm
+    std::string path;
+    if (int r = rt_jit_build(key, &path)) return r;
+    std::vector<char> image;
+    if (!read_file(path, image) || image.empty()) return rt_fail(RTPBR_ESTATE, "cannot read %s", path.c_str());
+    RT_HIP_TRY(hipSetDevice(c->device));
+    RtJitModule* m = new RtJitModule();
+    hipError_t e = hipModuleLoadData(&m->module, image.data());
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->trace, m->module, "rt_jit_trace");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->primary, m->module, "rt_jit_primary");
+    if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->trace_blocks_per_cu, m->trace, 256, 0);
+    if (e != hipSuccess) {
+        delete m;
+        unlink(path.c_str());                        // a stale / foreign code object: recompile next time
+        return rt_fail_hip("loading the run-time compiled code object", e);
+    }
+    m->path = path;
+    g_modules[id] = m;
+    *out = m;
+    return RTPBR_OK;
+}
+
+int rt_jit_launch(hipFunction_t f, const Params& P, unsigned grid, hipStream_t st) {
+    Params copy = P;                                  // the launch reads the argument during the call only
+    void* args[] = {&copy};
+    RT_HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+    return RTPBR_OK;
+}
+
+// test hook (no device needed): compile the code object of a key and return its path
+extern "C" int rtpbr_test_jit_build(int kind, int n_obj, unsigned long long types, unsigned sig, int cull, int waves, char* path_out, size_t cap) {
+    RtJitKey k{kind, n_obj, types, sig, cull, waves};
+    std::string p;
+    if (int r = rt_jit_build(k, &p)) return r;
+    if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());
+    return RTPBR_OK;
+}

@@ -1,0 +1,20 @@
+// rt_jit_tu.hip — the translation unit rtpbr compiles AT RUN TIME for one scene (rt_jit.hip drives hipcc --genco).
+// Everything the ahead-of-time library specialises only for listed cases is a compile-time constant here:
+//   RT_JIT_KIND   KIND_BOXES (all boxes: nearest box on squared distances) or KIND_GENERIC (analytic shapes)
+//   RT_JIT_NOBJ   the object count (the object loop is fully unrolled, two objects per scalar-load group)
+//   RT_JIT_TYPES  (shape type + 1) in 4 bits per object: the per-object shape switch disappears
+//   RT_JIT_SIG    rotation class in 3 bits per object: identity / single-axis rotations use 0 / 4 of the 9 products
+//                 and the packed object table (rt_types.hpp)
+//   RT_JIT_CULL   the camera rays' wave-level Lipschitz culling is valid for this scene (host check)
+//   RT_JIT_WAVES  waves per SIMD the pool kernel is compiled for
+// Same arithmetic as the ahead-of-time instances: results are bit-identical (tests/test_gpu_jit.py).
+#include "rt_trace.hpp"
+
+namespace rt {
+extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES) rt_jit_trace(const Params P) {
+    trace_paths_pool_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG>(P);
+}
+extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P) {
+    primary_rays_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(P);
+}
+}  // namespace rt

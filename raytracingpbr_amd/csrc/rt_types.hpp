@@ -52,6 +52,13 @@ constexpr int sig_offset(uint32_t sig, int i) {
     return o;
 }
 
+// Run-time compiled instances (rt_jit.hip) know every object's SHAPE TYPE at compile time as well: RT_JIT_TYPES holds
+// (type + 1) in 4 bits per object, 0 = "read the type from the table" (ahead-of-time instances: always 0).
+#ifndef RT_JIT_TYPES
+#define RT_JIT_TYPES 0ull
+#endif
+constexpr int jit_type(int i) { return i < 16 ? (int)((RT_JIT_TYPES >> (4 * i)) & 15ull) - 1 : -1; }
+
 // 16 dwords: what one march step needs from one object
 struct ObjM {
     float px, py, pz;

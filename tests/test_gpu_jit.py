@@ -1,0 +1,100 @@
+"""Per-scene instances compiled at run time (rt_jit.hip; run with -m gpu): any scene of <= 8 analytic shapes gets the
+unrolled kernels with its object count, shape types and rotation classes as compile-time constants; results must be
+bit-identical to the ahead-of-time instances and to the oracle, and the code objects are cached on disk."""
+import glob
+import os
+import time
+
+import numpy as np
+import pytest
+
+from cases import case_by_name
+from fuzz import random_box8_case, random_case, run
+from oracle_backend import OracleRenderer
+from raytracingpbr_amd import SHAPE, Config, Material, Renderer, Scene, SDFObject, Transform, cornell_box
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def axis_aligned_boxes(seed):
+    """8 boxes whose rotations are multiples of 90 degrees about one axis (classes identity / X / Y / Z) — NOT the
+    listed ahead-of-time signature"""
+    rng = np.random.default_rng(seed)
+    objs = []
+    for i in range(8):
+        axis = int(rng.integers(0, 4))
+        rot = [0.0, 0.0, 0.0]
+        if axis < 3:
+            rot[axis] = float(rng.choice([90.0, -90.0, 180.0, 37.0]))
+        pos = tuple(float(v) for v in rng.uniform(-6, 6, 3))
+        size = tuple(float(v) for v in rng.uniform(0.5, 3.0, 3))
+        alb = tuple(float(v) for v in rng.uniform(0.2, 0.9, 3))
+        em = (30.0, 30.0, 30.0) if i == 7 else (1.0, 1.0, 1.0)
+        objs.append(SDFObject(SHAPE.BOX, Transform(pos, tuple(rot), size), Material(alb, em, 1.0, 0.0, 0.0, 1.5)))
+    sc = cornell_box("v3", aspect=96 / 54)
+    return Scene(objs, False, sc.camera, "axis_boxes")
+
+
+def test_axis_aligned_box_scene_gets_its_own_instance(tmp_path, monkeypatch):
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    sc = axis_aligned_boxes(3)
+    cfg = Config.cornell_v3(96, 54, seed=5, max_raytrace=6)
+    o = OracleRenderer(sc, cfg); o.sample(4)
+    a = Renderer(sc, cfg); a.set_option("jit", 0); a.sample(4)              # ahead-of-time general instance
+    assert a.counter("jit_active") == 0
+    t0 = time.time()
+    j = Renderer(sc, cfg); j.set_option("jit", 1); j.set_option("primary_split", 2); j.sample(4)
+    t_first = time.time() - t0
+    assert j.counter("jit_active") == 1
+    assert np.array_equal(bits(j.image_buffer), bits(o.image_buffer))
+    assert np.array_equal(bits(a.image_buffer), bits(o.image_buffer))
+    files = glob.glob(str(tmp_path / "k1_n8_*.hsaco"))
+    assert len(files) == 1, files
+    # the default (-1) also compiles here: no listed ahead-of-time signature fits this scene
+    d = Renderer(sc, cfg); d.sample(4)
+    assert d.counter("jit_active") == 1 and np.array_equal(bits(d.image_buffer), bits(o.image_buffer))
+    # ... but not for the Cornell Box, which the listed signature serves
+    c = Renderer(cornell_box("v3"), Config.cornell_v3(64, 64, 0, 4)); c.sample(2)
+    assert c.counter("jit_active") == 0
+    print(f"first use (compile + load) {t_first:.1f} s")
+
+
+def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    case = case_by_name("tokyo_ibl_env")
+    o = OracleRenderer(case.scene, case.cfg); case.run(o)
+    g = Renderer(case.scene, case.cfg); g.set_option("jit", 1); g.set_option("primary_split", 2); case.run(g)
+    assert g.counter("jit_active") == 1
+    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+    assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
+    files = glob.glob(str(tmp_path / "k0_n7_*.hsaco"))
+    assert len(files) == 1
+    stamp = os.path.getmtime(files[0])
+    # same key again (same process: module map; the file is not rebuilt)
+    g2 = Renderer(case.scene, case.cfg); g2.set_option("jit", 1); case.run(g2)
+    assert g2.counter("jit_active") == 1 and os.path.getmtime(files[0]) == stamp
+    assert np.array_equal(bits(g2.image_buffer), bits(o.image_buffer))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzzed_scenes_through_run_time_instances(seed, tmp_path, monkeypatch):
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    sc, cfg, env, n = random_case(100 + seed) if seed % 2 else random_box8_case(100 + seed)
+    analytic = all(ob.type != SHAPE.BUNNY for ob in sc.objects)
+    if cfg.kernel_form != 0 or len(sc.objects) > 8 or not analytic:
+        pytest.skip("complete-path scenes of <= 8 analytic shapes only")
+    o = run(OracleRenderer(sc, cfg), env, n, False)
+    g = Renderer(sc, cfg)
+    g.set_option("jit", 1)
+    if seed % 4 < 2:
+        g.set_option("primary_split", 2)
+    g = run(g, env, n, False)
+    assert g.counter("jit_active") == 1
+    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+    assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
+    cg, co = g.counters(), o.counters()
+    assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups) == (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups)

@@ -381,6 +381,7 @@ def test_fuzz_random_scenes_match_oracle(seed):
     from fuzz import random_case, run
     sc, cfg, env, n = random_case(seed)
     g = Renderer(sc, cfg)
+    g.set_option("jit", 0)                    # the ahead-of-time instances (run-time compiled ones: test_gpu_jit.py)
     if seed % 2:
         g.set_option("primary_split", 2)      # small frames: force the separate primary-raycast kernel on half of the cases
     g = run(g, env, n, cfg.kernel_form == 1)
@@ -406,6 +407,7 @@ def test_fuzz_eight_box_scenes_match_oracle(seed):
     co = o.counters()
     for opts in ({}, {"primary_split": 2}, {"lazy_sqrt": 0, "specialize": 0}):
         g = Renderer(sc, cfg)
+        g.set_option("jit", 0)
         for k, v in opts.items():
             g.set_option(k, v)
         g = run(g, env, n, cfg.kernel_form == 1)

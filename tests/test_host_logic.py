@@ -215,3 +215,29 @@ def test_render_interactive_frame_refreshes_while_moving():
         counts.append(float(r.image_buffer[..., 3].max()))
     # deposits accumulate while at rest, drop to (almost) nothing each frame while the pose moves, grow again after
     assert counts[4] >= 1 and min(counts[6:20]) <= 1 and counts[-1] >= counts[25]
+
+
+def test_run_time_instance_compiles_without_a_gpu(tmp_path, monkeypatch):
+    """rt_jit.hip: hipcc --genco of rt_jit_tu.hip for a scene key (here the 7-object Tokyo scene: 4 spheres, 2 boxes,
+    1 cylinder, all rotations identity) lands in the cache directory; a second request is a cache hit."""
+    import ctypes as C
+    import time
+    from raytracingpbr_amd import _capi
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    f = lib.rtpbr_test_jit_build
+    f.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(512)
+    t0 = time.time()
+    assert f(0, 7, 0x4332222, 0x249249, 1, 5, buf, 512) == 0, lib.rtpbr_last_error()
+    t_build = time.time() - t0
+    path = buf.value.decode()
+    assert path.startswith(str(tmp_path)) and os.path.getsize(path) > 10000
+    assert open(path, "rb").read(4) in (b"\x7fELF", b"__CL")       # code object, or clang offload bundle around it
+    t0 = time.time()
+    assert f(0, 7, 0x4332222, 0x249249, 1, 5, buf, 512) == 0 and buf.value.decode() == path
+    assert time.time() - t0 < 0.5 <= max(t_build, 0.5)
+    # no compiler: a clear error for a key that is not cached (the library then keeps its ahead-of-time instance)
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    lib.rtpbr_last_error.restype = C.c_char_p
+    assert f(0, 3, 0x222, 0x49, 1, 5, buf, 512) != 0 and b"run-time compilation failed" in lib.rtpbr_last_error()
