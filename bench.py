@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--swap-lanes", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="rtpbr_set_option knob (A/B runs), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-jit", action="store_true", help="use the ahead-of-time kernels instead of the run-time compiled, scene-specialised ones")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --backend gloo)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -140,6 +141,12 @@ def main():
         r.set_option("shade_lanes", a.shade_lanes)
     if a.swap_lanes:
         r.set_option("swap_lanes", a.swap_lanes)
+    if not a.no_jit:
+        # production setting for an offline render of a fixed scene: the complete-path kernels compiled at run time for
+        # THIS scene and configuration (rt_jit.hip: ~2 s once, then a disk cache), as Taichi JIT-compiles the reference's
+        # kernels; falls back to the ahead-of-time instance if hipcc is not available on the box
+        r.set_option("jit", 1)
+        r.set_option("jit_bake", 1)
     for kv in a.opt:
         k, v = kv.split("=")
         r.set_option(k, int(v))
@@ -221,6 +228,8 @@ def main():
                                    f"seed 0; one step = refresh + {SPP} spp trace + ordered accumulation"
                                    + (f" + 1 RCCL gather of {world} tile sets" if world > 1 else ""),
                        "parallelism": f"tiles{world}" if world > 1 else "single",
+                       "kernels": "run-time compiled for this scene (object table and render configuration baked)" if r.counter("jit_active")
+                                  else "ahead-of-time instances",
                        "raycasts_per_sample": round(B, 3), "march_steps_per_raycast": round(S, 3)},
             # the binding roofline: FP32 vector issue.  achieved = algorithmic FLOPs per launch / HIP-event time of the
             # kernels that do them (primary_rays + trace_paths_pool); traffic = HBM bytes per launch of the dominant kernel

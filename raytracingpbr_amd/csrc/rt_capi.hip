@@ -524,32 +524,6 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.cull_ok = ok ? 1 : 0;
         P.cull_extent = 4.0f * ext;
     }
-    // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
-    c->jit_mod = nullptr;
-    if (c->jit != 0 && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && P.scheduler == 1 && c->n_obj <= 8 &&
-        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC)) {
-        const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
-        if (c->jit == 1 || !aot_special) {
-            RtJitKey key{};
-            key.kind = c->kind;
-            key.n_obj = c->n_obj;
-            for (int i = 0; i < c->n_obj; i++) {
-                key.types |= (unsigned long long)(c->objm[i].type + 1) << (4 * i);
-                key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
-            }
-            key.cull = P.cull_ok;
-            key.waves = c->kind == KIND_BOXES ? 6 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
-            RtJitModule* jm = nullptr;
-            const int r = rt_jit_acquire(c, key, &jm);
-            if (r == RTPBR_OK) {
-                c->jit_mod = jm;
-                P.box_sig = key.sig;
-            } else if (c->jit == 1) {
-                return r;
-            }
-        }
-    }
-    pack_objects(c, P);
     {
         const float rho = c->cfg.box_round;
         P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
@@ -561,6 +535,44 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.box_rho2m *= 4.0f;
         P.box_4rho2m *= 4.0f;
     }
+    // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
+    c->jit_mod = nullptr;
+    if (c->jit != 0 && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && P.scheduler == 1 && c->n_obj <= 8 &&
+        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC)) {
+        const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
+        if (c->jit >= 1 || !aot_special) {
+            RtJitKey key{};
+            key.kind = c->kind;
+            key.n_obj = c->n_obj;
+            for (int i = 0; i < c->n_obj; i++) {
+                key.types |= (unsigned long long)(c->objm[i].type + 1) << (4 * i);
+                key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
+            }
+            key.cull = P.cull_ok;
+            key.waves = c->kind == KIND_BOXES ? 6 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
+            key.baked = c->jit_bake;
+            key.table = reinterpret_cast<const unsigned*>(c->objm);
+            if (key.baked) {
+                rtpbr_config b = c->cfg;
+                b.seed = 0;
+                b.frame = 0;
+                memcpy(key.cfg_words, &b, sizeof b);
+                key.extra[0] = (unsigned)P.box_lazy;
+                memcpy(&key.extra[1], &P.box_four_rho, 4);
+                memcpy(&key.extra[2], &P.box_rho2m, 4);
+                memcpy(&key.extra[3], &P.box_4rho2m, 4);
+            }
+            RtJitModule* jm = nullptr;
+            const int r = rt_jit_acquire(c, key, &jm);
+            if (r == RTPBR_OK) {
+                c->jit_mod = jm;
+                P.box_sig = key.sig;
+            } else if (c->jit == 2) {
+                return r;
+            }
+        }
+    }
+    pack_objects(c, P);
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
@@ -855,8 +867,13 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "lazy_sqrt must be 0 or 1");
         c->lazy_sqrt = (int)value;
     } else if (!strcmp(key, "jit")) {
-        if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "jit must be -1 (when no ahead-of-time specialisation fits), 0 (never) or 1 (always)");
+        if (value < -1 || value > 2)
+            return fail(RTPBR_EINVAL, "jit must be -1 (when no ahead-of-time specialisation fits), 0 (never), 1 (always, falling back to the "
+                                      "ahead-of-time instance if compilation is impossible) or 2 (always, an error otherwise)");
         c->jit = (int)value;
+    } else if (!strcmp(key, "jit_bake")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "jit_bake must be 0 or 1");
+        c->jit_bake = (int)value;
     } else if (!strcmp(key, "specialize")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "specialize must be 0 or 1");
         c->specialize = (int)value;

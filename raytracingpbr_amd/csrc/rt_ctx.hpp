@@ -32,6 +32,10 @@ struct RtJitKey {
     unsigned long long types;   // (shape type + 1) in 4 bits per object
     unsigned sig;               // rotation class in 3 bits per object
     int cull, waves;
+    int baked;                  // 1: the march table and the render configuration are baked into the code object
+    const unsigned* table;      // n_obj x 16 words (ObjM blocks)
+    unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed
+    unsigned extra[4];          // box_lazy, box_four_rho, box_rho2m, box_4rho2m (bit patterns)
 };
 struct RtJitModule {
     hipModule_t module = nullptr;
@@ -113,6 +117,7 @@ struct rtpbr_ctx {
     // run-time compiled instance of the current scene (rt_jit.hip): -1 = when no ahead-of-time specialisation serves
     // the scene, 0 = never, 1 = always (an error if it cannot be built)
     int jit = -1;
+    int jit_bake = 0;                 // 1: run-time instances carry the scene's constants as literals
     RtJitModule* jit_mod = nullptr;   // the one the last rtpbr_sample() used (nullptr = ahead-of-time instance)
     unsigned jit_sig = 0;
     // multi-GPU gather (rt_rccl.hip): communicator handle (ncclComm_t) and the packed-tile buffers

@@ -355,6 +355,18 @@ typedef float f8u __attribute__((ext_vector_type(8), aligned(4)));
 typedef float f2u_ __attribute__((ext_vector_type(2), aligned(4)));
 template <uint32_t SIG, int I>
 RT_D ObjM load_obj(ObjTab tab) {
+#if RT_JIT_BAKED
+    {
+        auto w = [](int k) { return __builtin_bit_cast(float, RT_JIT_TABLE_BITS[I][k]); };
+        ObjM o = {};
+        o.px = w(0), o.py = w(1), o.pz = w(2);
+#pragma unroll
+        for (int k = 0; k < 9; k++) o.m[k] = w(3 + k);
+        o.sx = w(12), o.sy = w(13), o.sz = w(14);
+        o.type = (int32_t)RT_JIT_TABLE_BITS[I][15];
+        return o;
+    }
+#endif
     if constexpr (SIG == 0) {
         return tab[I];
     } else {

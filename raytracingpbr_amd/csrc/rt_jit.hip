@@ -109,9 +109,16 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
     const std::string dir = lib_dir();
     uint64_t sh = 0;
     if (!source_hash(dir, &sh)) return rt_fail(RTPBR_ESTATE, "run-time compilation: kernel sources not found next to the library (%s)", dir.c_str());
+    uint64_t th = 0;
+    if (key.baked) {
+        th = 1469598103934665603ull;
+        for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
+        for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
+        for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
+    }
     char name[256];
-    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig, key.cull,
-             key.waves, (unsigned long long)sh);
+    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, (unsigned long long)th, (unsigned long long)sh);
     const std::string cdir = cache_dir();
     const std::string path = cdir + "/" + name + ".hsaco";
     if (access(path.c_str(), R_OK) == 0) {
@@ -122,6 +129,33 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
     const std::string tpath = path + tmp, log = path + ".log";
+    std::string table_def;
+    if (key.baked) {
+        const std::string tfile = path + ".table.hpp";
+        FILE* f = fopen(tfile.c_str(), "w");
+        if (!f) return rt_fail(RTPBR_ESTATE, "cannot write %s", tfile.c_str());
+        fprintf(f, "// generated by rt_jit.hip: the scene's march table (ObjM blocks) as bit patterns\n");
+        fprintf(f, "static constexpr uint32_t RT_JIT_TABLE_BITS[%d][16] = {\n", key.n_obj);
+        for (int i = 0; i < key.n_obj; i++) {
+            fprintf(f, "    {");
+            for (int k = 0; k < 16; k++) fprintf(f, "0x%08xu%s", key.table[i * 16 + k], k < 15 ? ", " : "");
+            fprintf(f, "},\n");
+        }
+        fprintf(f, "};\n");
+        // the render configuration (every knob of rtpbr_config except seed and frame, which stay launch arguments) and the
+        // constants derived from it: branches on the variant knobs fold away, thresholds become literals
+        fprintf(f, "struct RtJitCfgWords { uint32_t w[%d]; };\n", (int)(sizeof(rtpbr_config) / 4));
+        fprintf(f, "static constexpr RtJitCfgWords RT_JIT_CFG_WORDS = {{");
+        for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) fprintf(f, "0x%08xu%s", key.cfg_words[k], k + 1 < sizeof(rtpbr_config) / 4 ? ", " : "");
+        fprintf(f, "}};\n");
+        fprintf(f, "#define RT_JIT_BAKE_PARAMS(Q) do { rtpbr_config b_ = __builtin_bit_cast(rtpbr_config, RT_JIT_CFG_WORDS); "
+                   "b_.seed = (Q).cfg.seed; b_.frame = (Q).cfg.frame; (Q).cfg = b_; (Q).n_obj = %d; "
+                   "(Q).box_lazy = %d; (Q).box_four_rho = __builtin_bit_cast(float, 0x%08xu); (Q).box_rho2m = __builtin_bit_cast(float, 0x%08xu); "
+                   "(Q).box_4rho2m = __builtin_bit_cast(float, 0x%08xu); } while (0)\n",
+                key.n_obj, key.extra[0], key.extra[1], key.extra[2], key.extra[3]);
+        fclose(f);
+        table_def = "-DRT_JIT_TABLE_FILE=\"" + tfile + "\"";
+    }
     char d[6][64];
     snprintf(d[0], 64, "-DRT_JIT_KIND=%d", key.kind);
     snprintf(d[1], 64, "-DRT_JIT_NOBJ=%d", key.n_obj);
@@ -133,6 +167,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
     std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
                                      "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-unused-value",
                                      d[0], d[1], d[2], d[3], d[4], d[5], dir + "/rt_jit_tu.hip", "-o", tpath};
+    if (key.baked) argv.insert(argv.begin() + 10, table_def);
     const int rc = run(argv, log);
     if (rc != 0 || access(tpath.c_str(), R_OK) != 0) {
         unlink(tpath.c_str());
@@ -148,9 +183,16 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
 }
 
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
-    char id[192];
-    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig, key.cull,
-             key.waves);
+    uint64_t th = 0;
+    if (key.baked) {
+        th = 1469598103934665603ull;
+        for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
+        for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
+        for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
+    }
+    char id[224];
+    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, (unsigned long long)th);
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_modules.find(id);
     if (it != g_modules.end()) {
@@ -188,7 +230,8 @@ int rt_jit_launch(hipFunction_t f, const Params& P, unsigned grid, hipStream_t s
 
 // test hook (no device needed): compile the code object of a key and return its path
 extern "C" int rtpbr_test_jit_build(int kind, int n_obj, unsigned long long types, unsigned sig, int cull, int waves, char* path_out, size_t cap) {
-    RtJitKey k{kind, n_obj, types, sig, cull, waves};
+    RtJitKey k{};
+    k.kind = kind, k.n_obj = n_obj, k.types = types, k.sig = sig, k.cull = cull, k.waves = waves;
     std::string p;
     if (int r = rt_jit_build(k, &p)) return r;
     if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());

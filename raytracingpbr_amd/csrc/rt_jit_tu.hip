@@ -10,11 +10,21 @@
 // Same arithmetic as the ahead-of-time instances: results are bit-identical (tests/test_gpu_jit.py).
 #include "rt_trace.hpp"
 
+// With option "jit_bake" the generated header (RT_JIT_TABLE_FILE) also carries the march table and the render
+// configuration: RT_JIT_BAKE_PARAMS overwrites those fields of a local copy of the launch arguments with compile-time
+// constants, and constant propagation does the rest (variant branches fold, thresholds become literals).
+#ifndef RT_JIT_BAKE_PARAMS
+#define RT_JIT_BAKE_PARAMS(Q)
+#endif
 namespace rt {
 extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES) rt_jit_trace(const Params P) {
-    trace_paths_pool_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG>(P);
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    trace_paths_pool_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG>(Q);
 }
 extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P) {
-    primary_rays_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(P);
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    primary_rays_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(Q);
 }
 }  // namespace rt

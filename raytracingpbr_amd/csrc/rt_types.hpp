@@ -58,6 +58,15 @@ constexpr int sig_offset(uint32_t sig, int i) {
 #define RT_JIT_TYPES 0ull
 #endif
 constexpr int jit_type(int i) { return i < 16 ? (int)((RT_JIT_TYPES >> (4 * i)) & 15ull) - 1 : -1; }
+// ... and, with option "jit_bake", the march table itself: RT_JIT_TABLE_FILE is a generated header that defines
+//   static constexpr uint32_t RT_JIT_TABLE_BITS[RT_JIT_NOBJ][16]     (the ObjM blocks, bit patterns)
+// so that positions, matrix entries and sizes become instruction literals (no scalar loads, no SGPRs for them).
+#ifdef RT_JIT_TABLE_FILE
+#include RT_JIT_TABLE_FILE
+#define RT_JIT_BAKED 1
+#else
+#define RT_JIT_BAKED 0
+#endif
 
 // 16 dwords: what one march step needs from one object
 struct ObjM {

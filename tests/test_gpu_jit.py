@@ -47,7 +47,7 @@ def test_axis_aligned_box_scene_gets_its_own_instance(tmp_path, monkeypatch):
     a = Renderer(sc, cfg); a.set_option("jit", 0); a.sample(4)              # ahead-of-time general instance
     assert a.counter("jit_active") == 0
     t0 = time.time()
-    j = Renderer(sc, cfg); j.set_option("jit", 1); j.set_option("primary_split", 2); j.sample(4)
+    j = Renderer(sc, cfg); j.set_option("jit", 2); j.set_option("primary_split", 2); j.sample(4)
     t_first = time.time() - t0
     assert j.counter("jit_active") == 1
     assert np.array_equal(bits(j.image_buffer), bits(o.image_buffer))
@@ -63,11 +63,45 @@ def test_axis_aligned_box_scene_gets_its_own_instance(tmp_path, monkeypatch):
     print(f"first use (compile + load) {t_first:.1f} s")
 
 
+@pytest.mark.parametrize("name", ["c1_cornell_v3_256_16spp_4b", "cornell_v3_8b_wide", "cornell_v2", "cornell_v1_128b", "cornell_shortest",
+                                  "scene_demo_gradient", "tokyo_ibl_env"])
+def test_baked_instances_match_oracle_and_golden(name, tmp_path, monkeypatch):
+    """option jit_bake: the scene's march table and the whole render configuration (every variant knob) as compile-time
+    constants — every complete-path variant of the reference, fused and split primary kernels"""
+    from test_oracle_golden import check_fingerprint
+    from cases import fingerprint
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    case = case_by_name(name)
+    o = OracleRenderer(case.scene, case.cfg); case.run(o)
+    for split in (0, 2):
+        g = Renderer(case.scene, case.cfg)
+        g.set_option("jit", 2); g.set_option("jit_bake", 1); g.set_option("primary_split", split)
+        case.run(g)
+        assert g.counter("jit_active") == 1
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), split
+        assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels)), split
+        cg, co = g.counters(), o.counters()
+        assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
+               (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits)
+        check_fingerprint(fingerprint(g), case.name)
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 1 and len(glob.glob(str(tmp_path / "*.table.hpp"))) == 1
+    # a different seed or frame number does not recompile (they stay launch arguments) ...
+    g = Renderer(case.scene, case.cfg.copy(seed=case.cfg.seed + 1))
+    g.set_option("jit", 2); g.set_option("jit_bake", 1); case.run(g)
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 1
+    o2 = OracleRenderer(case.scene, case.cfg.copy(seed=case.cfg.seed + 1)); case.run(o2)
+    assert np.array_equal(bits(g.image_buffer), bits(o2.image_buffer))
+    # ... any other knob does
+    g = Renderer(case.scene, case.cfg.copy(max_raytrace=case.cfg.max_raytrace + 1))
+    g.set_option("jit", 2); g.set_option("jit_bake", 1); case.run(g)
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 2
+
+
 def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
     monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     case = case_by_name("tokyo_ibl_env")
     o = OracleRenderer(case.scene, case.cfg); case.run(o)
-    g = Renderer(case.scene, case.cfg); g.set_option("jit", 1); g.set_option("primary_split", 2); case.run(g)
+    g = Renderer(case.scene, case.cfg); g.set_option("jit", 2); g.set_option("primary_split", 2); case.run(g)
     assert g.counter("jit_active") == 1
     assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
     assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
@@ -75,12 +109,12 @@ def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
     assert len(files) == 1
     stamp = os.path.getmtime(files[0])
     # same key again (same process: module map; the file is not rebuilt)
-    g2 = Renderer(case.scene, case.cfg); g2.set_option("jit", 1); case.run(g2)
+    g2 = Renderer(case.scene, case.cfg); g2.set_option("jit", 2); case.run(g2)
     assert g2.counter("jit_active") == 1 and os.path.getmtime(files[0]) == stamp
     assert np.array_equal(bits(g2.image_buffer), bits(o.image_buffer))
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(16))
 def test_fuzzed_scenes_through_run_time_instances(seed, tmp_path, monkeypatch):
     monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     sc, cfg, env, n = random_case(100 + seed) if seed % 2 else random_box8_case(100 + seed)
@@ -89,7 +123,8 @@ def test_fuzzed_scenes_through_run_time_instances(seed, tmp_path, monkeypatch):
         pytest.skip("complete-path scenes of <= 8 analytic shapes only")
     o = run(OracleRenderer(sc, cfg), env, n, False)
     g = Renderer(sc, cfg)
-    g.set_option("jit", 1)
+    g.set_option("jit", 2)
+    g.set_option("jit_bake", seed // 2 % 2)
     if seed % 4 < 2:
         g.set_option("primary_split", 2)
     g = run(g, env, n, False)
