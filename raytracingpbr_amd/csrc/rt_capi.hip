@@ -537,8 +537,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     }
     // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
     c->jit_mod = nullptr;
+    const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1 && c->mlp_mfma;   // configuration baking only
     if (c->jit != 0 && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && P.scheduler == 1 && c->n_obj <= 8 &&
-        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC)) {
+        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || jit_bunny)) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
         if (c->jit >= 1 || !aot_special) {
             RtJitKey key{};
@@ -549,7 +550,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
             }
             key.cull = P.cull_ok;
-            key.waves = c->kind == KIND_BOXES ? 6 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
+            if (jit_bunny) key.sig = 0;
+            key.waves = c->kind == KIND_BOXES ? 6 : c->kind == KIND_BUNNY ? 4 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
             key.baked = c->jit_bake;
             key.table = reinterpret_cast<const unsigned*>(c->objm);
             if (key.baked) {

@@ -17,14 +17,16 @@
 #define RT_JIT_BAKE_PARAMS(Q)
 #endif
 namespace rt {
+// the neural-SDF kinds keep their own object handling (one object, table row 0): no unrolled object loop
+constexpr int TU_NOBJ = (RT_JIT_KIND == KIND_BUNNY || RT_JIT_KIND == KIND_MIXED) ? 0 : RT_JIT_NOBJ;
 extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES) rt_jit_trace(const Params P) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);
-    trace_paths_pool_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG>(Q);
+    trace_paths_pool_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q);
 }
 extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);
-    primary_rays_impl<RT_JIT_KIND, RT_JIT_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(Q);
+    primary_rays_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(Q);
 }
 }  // namespace rt

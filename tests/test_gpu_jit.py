@@ -64,7 +64,7 @@ def test_axis_aligned_box_scene_gets_its_own_instance(tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["c1_cornell_v3_256_16spp_4b", "cornell_v3_8b_wide", "cornell_v2", "cornell_v1_128b", "cornell_shortest",
-                                  "scene_demo_gradient", "tokyo_ibl_env"])
+                                  "scene_demo_gradient", "tokyo_ibl_env", "bunny_glass", "bunny_chrome_frame30"])
 def test_baked_instances_match_oracle_and_golden(name, tmp_path, monkeypatch):
     """option jit_bake: the scene's march table and the whole render configuration (every variant knob) as compile-time
     constants — every complete-path variant of the reference, fused and split primary kernels"""
