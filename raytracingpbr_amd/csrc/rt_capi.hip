@@ -563,6 +563,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 memcpy(&key.extra[1], &P.box_four_rho, 4);
                 memcpy(&key.extra[2], &P.box_rho2m, 4);
                 memcpy(&key.extra[3], &P.box_4rho2m, 4);
+                const int ints[7] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes};
+                memcpy(key.ints, ints, sizeof ints);
             }
             RtJitModule* jm = nullptr;
             const int r = rt_jit_acquire(c, key, &jm);

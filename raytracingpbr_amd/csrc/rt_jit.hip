@@ -115,6 +115,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
         for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
         for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
         for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
+        for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
     }
     char name[256];
     snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
@@ -151,8 +152,11 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
         fprintf(f, "#define RT_JIT_BAKE_PARAMS(Q) do { rtpbr_config b_ = __builtin_bit_cast(rtpbr_config, RT_JIT_CFG_WORDS); "
                    "b_.seed = (Q).cfg.seed; b_.frame = (Q).cfg.frame; (Q).cfg = b_; (Q).n_obj = %d; "
                    "(Q).box_lazy = %d; (Q).box_four_rho = __builtin_bit_cast(float, 0x%08xu); (Q).box_rho2m = __builtin_bit_cast(float, 0x%08xu); "
-                   "(Q).box_4rho2m = __builtin_bit_cast(float, 0x%08xu); } while (0)\n",
-                key.n_obj, key.extra[0], key.extra[1], key.extra[2], key.extra[3]);
+                   "(Q).box_4rho2m = __builtin_bit_cast(float, 0x%08xu); "
+                   "(Q).tile_w = %d; (Q).tile_h = %d; (Q).ntx = %d; (Q).nty = %d; (Q).world = %d; (Q).shade_lanes = %d; (Q).swap_lanes = %d; "
+                   "} while (0)\n",
+                key.n_obj, key.extra[0], key.extra[1], key.extra[2], key.extra[3], key.ints[0], key.ints[1], key.ints[2], key.ints[3],
+                key.ints[4], key.ints[5], key.ints[6]);
         fclose(f);
         table_def = "-DRT_JIT_TABLE_FILE=\"" + tfile + "\"";
     }
@@ -189,6 +193,7 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
         for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
         for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
         for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
+        for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
     }
     char id[224];
     snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
