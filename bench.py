@@ -219,6 +219,8 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except Exception:
             pass
+        jit_on = bool(r.counter("jit_active"))
+        kname, pname = ("rt_jit_trace", "rt_jit_primary") if jit_on else ("trace_paths_pool", "primary_rays")
         out = {
             "metric": f"Msamples/sec (pixels x spp / s), Cornell Box {W}x{H}",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -228,15 +230,15 @@ def main():
                                    f"seed 0; one step = refresh + {SPP} spp trace + ordered accumulation"
                                    + (f" + 1 RCCL gather of {world} tile sets" if world > 1 else ""),
                        "parallelism": f"tiles{world}" if world > 1 else "single",
-                       "kernels": "run-time compiled for this scene (object table and render configuration baked)" if r.counter("jit_active")
+                       "kernels": "run-time compiled for this scene (object table and render configuration baked)" if jit_on
                                   else "ahead-of-time instances",
                        "raycasts_per_sample": round(B, 3), "march_steps_per_raycast": round(S, 3)},
             # the binding roofline: FP32 vector issue.  achieved = algorithmic FLOPs per launch / HIP-event time of the
             # kernels that do them (primary_rays + trace_paths_pool); traffic = HBM bytes per launch of the dominant kernel
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "trace_paths_pool", "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches_timed": launches,
-                         "kernels": "primary_rays + trace_paths_pool",
+                         "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches_timed": launches,
+                         "kernels": f"{pname} + {kname}",
                          "primary_rays_avg_launch_ms": round(primary_ms / max(primary_launches, 1), 3),
                          "primary_rays_launches_timed": primary_launches,
                          "algorithmic_flop_per_sample": round(flop_per_sample),
@@ -247,7 +249,7 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "achieved_counters": round(traffic / avg_launch_s / 1e9, 2) if traffic else None,
                     "frac_counters": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                    "traffic": traffic, "kernel": "trace_paths_pool"},
+                    "traffic": traffic, "kernel": kname},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, cfg, a.cpu_seconds)

@@ -52,8 +52,7 @@ def test_axis_aligned_box_scene_gets_its_own_instance(tmp_path, monkeypatch):
     assert j.counter("jit_active") == 1
     assert np.array_equal(bits(j.image_buffer), bits(o.image_buffer))
     assert np.array_equal(bits(a.image_buffer), bits(o.image_buffer))
-    files = glob.glob(str(tmp_path / "k1_n8_*.hsaco"))
-    assert len(files) == 1, files
+    assert len(glob.glob(str(tmp_path / "k1_n8_*.hsaco"))) <= 1     # (0 if an earlier test of this process built the key)
     # the default (-1) also compiles here: no listed ahead-of-time signature fits this scene
     d = Renderer(sc, cfg); d.sample(4)
     assert d.counter("jit_active") == 1 and np.array_equal(bits(d.image_buffer), bits(o.image_buffer))
@@ -84,17 +83,18 @@ def test_baked_instances_match_oracle_and_golden(name, tmp_path, monkeypatch):
         assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
                (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits)
         check_fingerprint(fingerprint(g), case.name)
-    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 1 and len(glob.glob(str(tmp_path / "*.table.hpp"))) == 1
+    n0 = len(glob.glob(str(tmp_path / "*.hsaco")))
+    assert n0 <= 1
     # a different seed or frame number does not recompile (they stay launch arguments) ...
     g = Renderer(case.scene, case.cfg.copy(seed=case.cfg.seed + 1))
     g.set_option("jit", 2); g.set_option("jit_bake", 1); case.run(g)
-    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 1
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == n0
     o2 = OracleRenderer(case.scene, case.cfg.copy(seed=case.cfg.seed + 1)); case.run(o2)
     assert np.array_equal(bits(g.image_buffer), bits(o2.image_buffer))
     # ... any other knob does
     g = Renderer(case.scene, case.cfg.copy(max_raytrace=case.cfg.max_raytrace + 1))
     g.set_option("jit", 2); g.set_option("jit_bake", 1); case.run(g)
-    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == 2
+    assert len(glob.glob(str(tmp_path / "*.hsaco"))) == n0 + 1
 
 
 def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
@@ -105,13 +105,20 @@ def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
     assert g.counter("jit_active") == 1
     assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
     assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
+    # (the un-baked key of this scene may have been built earlier in this process — modules are shared per device — so
+    # the disk cache is checked with a configuration no other test uses)
+    cfg = case.cfg.copy(max_raytrace=37)
+    o2 = OracleRenderer(case.scene, cfg); o2.set_env(case.env, case.env_exposure, case.env_gamma); o2.sample(3)
+    g2 = Renderer(case.scene, cfg); g2.set_env(case.env, case.env_exposure, case.env_gamma)
+    g2.set_option("jit", 2); g2.set_option("jit_bake", 1); g2.sample(3)
     files = glob.glob(str(tmp_path / "k0_n7_*.hsaco"))
-    assert len(files) == 1
+    assert len(files) == 1 and g2.counter("jit_active") == 1
+    assert np.array_equal(bits(g2.image_buffer), bits(o2.image_buffer))
     stamp = os.path.getmtime(files[0])
-    # same key again (same process: module map; the file is not rebuilt)
-    g2 = Renderer(case.scene, case.cfg); g2.set_option("jit", 2); case.run(g2)
-    assert g2.counter("jit_active") == 1 and os.path.getmtime(files[0]) == stamp
-    assert np.array_equal(bits(g2.image_buffer), bits(o.image_buffer))
+    g3 = Renderer(case.scene, cfg); g3.set_env(case.env, case.env_exposure, case.env_gamma)
+    g3.set_option("jit", 2); g3.set_option("jit_bake", 1); g3.sample(3)
+    assert g3.counter("jit_active") == 1 and os.path.getmtime(files[0]) == stamp
+    assert np.array_equal(bits(g3.image_buffer), bits(o2.image_buffer))
 
 
 @pytest.mark.parametrize("seed", range(16))

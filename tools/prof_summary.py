@@ -77,13 +77,13 @@ if ctr:
             lines.append(f"{k[:60]:60s} {c:24s} per_dispatch={x['per_dispatch']:.4g} dispatches={x['dispatches']}")
     summary["counters"] = ctr
     for k, v in ctr.items():
-        if "trace_paths" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if ("trace_paths" in k or "rt_jit_trace" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             fe, wr = v["FETCH_SIZE"]["per_dispatch"] * 1024, v["WRITE_SIZE"]["per_dispatch"] * 1024
             summary["trace_paths_hbm_bytes_per_launch"] = {"fetch_raw": fe, "fetch_x2_corrected": 2 * fe, "write": wr,
                                                            "total_corrected": 2 * fe + wr}
             lines.append(f"\ntrace_paths HBM bytes per launch: FETCH {fe:.4g} (x2 gfx950 correction: {2 * fe:.4g})  WRITE {wr:.4g}")
     for k, v in ctr.items():
-        if "primary_rays" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if ("primary_rays" in k or "rt_jit_primary" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             fe, wr = v["FETCH_SIZE"]["per_dispatch"] * 1024, v["WRITE_SIZE"]["per_dispatch"] * 1024
             summary["primary_rays_hbm_bytes_per_launch"] = {"fetch_raw": fe, "fetch_x2_corrected": 2 * fe, "write": wr,
                                                             "total_corrected": 2 * fe + wr}
@@ -111,7 +111,7 @@ if bj and tp and "--keep-traffic" not in sys.argv:
         "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
         "workload": {"width": int(m.group(1)), "height": int(m.group(2)), "spp": int(m.group(3)), "bounces": int(m.group(4)),
                      "spp_per_launch": int(m.group(3)) * bj["steps"] / launches},
-        "kernel": [k for k in ctr if "trace_paths" in k][0],
+        "kernel": [k for k in ctr if "trace_paths" in k or "rt_jit_trace" in k][0],
         "fetch_bytes_raw": tp["fetch_raw"], "fetch_bytes_x2_gfx950": tp["fetch_x2_corrected"], "write_bytes": tp["write"],
         "hbm_bytes_per_launch": tp["total_corrected"],
         "primary_rays_hbm_bytes_per_launch": summary.get("primary_rays_hbm_bytes_per_launch"),
