@@ -538,8 +538,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
     c->jit_mod = nullptr;
     const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1 && c->mlp_mfma;   // configuration baking only
-    if (c->jit != 0 && c->cfg.kernel_form == RTPBR_FORM_COMPLETE_PATH && P.scheduler == 1 && c->n_obj <= 8 &&
-        (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || jit_bunny)) {
+    const bool persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
+    if (c->jit != 0 && (persistent || P.scheduler == 1) && c->n_obj <= 8 && (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || (jit_bunny && !persistent))) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
         if (c->jit >= 1 || !aot_special) {
             RtJitKey key{};
@@ -602,7 +602,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             const bool use_pool = c->scheduler == 1 || (c->scheduler < 0 && P.np >= (1 << 20));
             if (use_pool) {
                 // pool scheduler: work items are pixels, claimed in chunks by persistent waves
-                int per_cu = persistent_pool_blocks_per_cu(c->kind);
+                int per_cu = c->jit_mod ? c->jit_mod->persistent_blocks_per_cu : persistent_pool_blocks_per_cu(c->kind);
                 if (per_cu <= 0) per_cu = 2;
                 long long grid = (long long)per_cu * c->n_cu;
                 long long need = ((long long)P.np + 127) / 128;      // 128 contexts per wave
@@ -615,7 +615,12 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 if (chunk > 1024) chunk = 1024;
                 P.chunk = (uint32_t)chunk;
                 HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
-                launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+                if (c->jit_mod) {
+                    if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
+                } else
+                    launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+            } else if (c->jit_mod) {
+                if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
             } else
                 launch_persistent(P, c->kind, steps, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));

@@ -40,14 +40,15 @@ struct RtJitKey {
 };
 struct RtJitModule {
     hipModule_t module = nullptr;
-    hipFunction_t trace = nullptr, primary = nullptr;
-    int trace_blocks_per_cu = 0;
+    hipFunction_t trace = nullptr, primary = nullptr, persistent_pool = nullptr, persistent_steps = nullptr;
+    int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0;
     std::string path;
 };
 struct rtpbr_ctx;
 int rt_jit_build(const RtJitKey& key, std::string* out);
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out);
 int rt_jit_launch(hipFunction_t f, const rt::Params& P, unsigned grid, hipStream_t st);
+int rt_jit_launch_steps(hipFunction_t f, const rt::Params& P, int steps, unsigned grid, hipStream_t st);
 
 // error channel: thread-local message behind rtpbr_last_error() (defined in rt_capi.hip)
 int rt_fail(int code, const char* fmt, const char* a = "");

@@ -214,7 +214,10 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     hipError_t e = hipModuleLoadData(&m->module, image.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&m->trace, m->module, "rt_jit_trace");
     if (e == hipSuccess) e = hipModuleGetFunction(&m->primary, m->module, "rt_jit_primary");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_pool, m->module, "rt_jit_persistent_pool");
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_steps, m->module, "rt_jit_persistent_steps");
     if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->trace_blocks_per_cu, m->trace, 256, 0);
+    if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->persistent_blocks_per_cu, m->persistent_pool, 256, 0);
     if (e != hipSuccess) {
         delete m;
         unlink(path.c_str());                        // a stale / foreign code object: recompile next time
@@ -229,6 +232,13 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
 int rt_jit_launch(hipFunction_t f, const Params& P, unsigned grid, hipStream_t st) {
     Params copy = P;                                  // the launch reads the argument during the call only
     void* args[] = {&copy};
+    RT_HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
+    return RTPBR_OK;
+}
+
+int rt_jit_launch_steps(hipFunction_t f, const Params& P, int steps, unsigned grid, hipStream_t st) {
+    Params copy = P;
+    void* args[] = {&copy, &steps};
     RT_HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 256, 1, 1, 0, st, args, nullptr));
     return RTPBR_OK;
 }

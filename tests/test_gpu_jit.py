@@ -97,6 +97,26 @@ def test_baked_instances_match_oracle_and_golden(name, tmp_path, monkeypatch):
     assert len(glob.glob(str(tmp_path / "*.hsaco"))) == n0 + 1
 
 
+@pytest.mark.parametrize("name", ["src_persistent", "src_persistent_4steps_blackbg", "src_adaptive_sampling"])
+def test_persistent_ray_form_through_run_time_instances(name, tmp_path, monkeypatch):
+    """the src/ pipeline (pathtrace() launches, ray state in ray_buffer): both of its schedulers, plain and baked"""
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    case = case_by_name(name)
+    o = OracleRenderer(case.scene, case.cfg); case.run(o)
+    for sched in (0, 1):
+        for bake in (0, 1):
+            g = Renderer(case.scene, case.cfg)
+            g.set_option("jit", 2); g.set_option("jit_bake", bake); g.set_option("scheduler", sched)
+            case.run(g)
+            assert g.counter("jit_active") == 1
+            assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), (sched, bake)
+            assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), (sched, bake)
+            assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels)), (sched, bake)
+            cg, co = g.counters(), o.counters()
+            assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
+                   (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits)
+
+
 def test_tokyo_scene_instance_and_disk_cache(tmp_path, monkeypatch):
     monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     case = case_by_name("tokyo_ibl_env")
