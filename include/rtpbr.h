@@ -330,6 +330,13 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * for the scene's rotation signature when there is one), "lazy_sqrt" (1: all-box scenes pick the
  * nearest box on squared distances and take one exact square root per march step),
  * "mlp_mfma", "mlp_lanes" (neural SDF),
+ * "jit" (per-scene kernels compiled at run time by hipcc --genco from the sources next to the library — what Taichi's
+ * JIT does for the reference: object loop unrolled, each object's shape function and rotation class fixed at compile
+ * time, src/scene.py:44-56 — cached under $RTPBR_JIT_CACHE / ~/.cache/rtpbr: -1 (default) when no ahead-of-time
+ * specialisation serves the scene, 0 never, 1 always but falling back to the ahead-of-time kernels if compilation is
+ * impossible, 2 always and an error otherwise), "jit_bake" (1: the run-time instance also carries the scene's object
+ * table and the whole rtpbr_config except seed and frame as compile-time constants — one code object per scene and
+ * configuration; for offline renders of a fixed scene),
  * "reserve_spp" (allocate the staging of a call of that many samples per pixel now instead of on
  * first use), "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */
