@@ -309,9 +309,9 @@ int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n);
 
 /* Measurement hooks (SURVEY.md §5 tracing row, §8(d)). */
 int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking */
-/* One counter by name: the six above, plus "mlp_wave_evals" / "mlp_lane_evals" — passes of the wave-cooperative
- * neural-SDF network (bunny_sdf_glass.py:149-203 on the matrix cores) and the ray evaluations they were needed for;
- * their ratio / 64 is the lane utilisation of the MLP.  EINVAL for an unknown name. */
+/* One counter by name: the six above, plus "mlp_wave_evals" / "mlp_lane_evals" — 32-ray half passes of the
+ * wave-cooperative neural-SDF network (bunny_sdf_glass.py:149-203 on the matrix cores) and the ray evaluations they
+ * were needed for; their ratio / 32 is the slot utilisation of the MLP.  EINVAL for an unknown name. */
 int rtpbr_get_counter(rtpbr_ctx* ctx, const char* name, unsigned long long* out);
 /* Device time (HIP events on the context's stream) of the trace kernel launches and of
  * all kernels of the last rtpbr_sample() call, in milliseconds (blocking). */
@@ -329,7 +329,8 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * (default), 2 always), "specialize" (1: use the instance compiled
  * for the scene's rotation signature when there is one), "lazy_sqrt" (1: all-box scenes pick the
  * nearest box on squared distances and take one exact square root per march step),
- * "mlp_mfma", "mlp_lanes" (neural SDF),
+ * "mlp_mfma", "mlp_lanes" (neural SDF: run the network when this many lanes wait for it), "mlp_full" (compute both
+ * 32-slot halves of a pass when at least this many wait, else the first 32 by rank),
  * "jit" (per-scene kernels compiled at run time by hipcc --genco from the sources next to the library — what Taichi's
  * JIT does for the reference: object loop unrolled, each object's shape function and rotation class fixed at compile
  * time, src/scene.py:44-56 — cached under $RTPBR_JIT_CACHE / ~/.cache/rtpbr: -1 (default) when no ahead-of-time

@@ -533,11 +533,12 @@ static float sd_bunny(v3 p) {
             f0[k * 4 + j] = rto_sin_pi(a + b[12 + j]);
         }
     }
-    /* layers 1, 2: out_kj = sin(sum_m sum_i v_mi * M_m[i][j] + bias) [/1.4] + in_kj.  The 16-term sum is ONE fma
-     * chain from +0 in the order (i outer, m inner) — the order in which a 16x16x4 f32 MFMA that takes the previous
-     * layer's result registers directly as its B operand accumulates (rt_device.hpp bunny_mlp_wave); the division
-     * by the constant 1.4 is a multiplication by f32(1/1.4) (what LLVM's arcp fast-math flag, on by default in
-     * Taichi, makes of it).  Both are choices inside the rounding freedom the reference leaves;
+    /* layers 1, 2: out_kj = sin(bias + sum_m sum_i v_mi * M_m[i][j]) [/1.4] + in_kj.  The 16-term sum is ONE fma
+     * chain that STARTS FROM THE BIAS, in the order (i outer, m inner) — the order in which a 16x16x4 f32 MFMA that
+     * takes the bias as its C operand and the previous layer's result registers directly as its B operand accumulates
+     * (rt_device.hpp bunny_mlp_wave); "sin(..) / 1.4 + in" is one fma with f32(1/1.4) (what LLVM's arcp + contract
+     * fast-math flags, on by default in Taichi, make of it).  All are choices inside the rounding freedom the
+     * reference leaves;
      * tests/test_oracle_refpin.py::test_bunny_sdf_and_raycast holds the result to 2e-6 of the reference's own code. */
     const float* src = f0; float* dst = f1;
     for (int layer = 0; layer < 2; layer++) {
@@ -545,12 +546,12 @@ static float sd_bunny(v3 p) {
         for (int k = 0; k < 4; k++) {
             const float* bw = lw + k * 68;
             for (int j = 0; j < 4; j++) {
-                float acc = 0.0f;
+                float acc = bw[64 + j];                          /* the accumulator starts from the bias */
                 for (int i = 0; i < 4; i++)
                     for (int m = 0; m < 4; m++) acc = fmaf(src[m * 4 + i], bw[m * 16 + i * 4 + j], acc);
-                float sn = rto_sin_pi(acc + bw[64 + j]);
-                if (layer == 1) sn = sn * 0.714285731f;          /* f32(1/1.4) */
-                dst[k * 4 + j] = sn + src[k * 4 + j];
+                float sn = rto_sin_pi(acc);
+                dst[k * 4 + j] = layer == 1 ? fmaf(sn, 0.714285731f, src[k * 4 + j])      /* f32(1/1.4), contracted */
+                                            : sn + src[k * 4 + j];
             }
         }
         src = f1; dst = f2;

@@ -503,6 +503,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.shade_lanes = c->shade_lanes;
     P.swap_lanes = c->swap_lanes;
     P.mlp_lanes = c->mlp_lanes;
+    P.mlp_full = c->mlp_full;
     P.mlp_mfma = c->mlp_mfma;
     P.scheduler = c->scheduler < 0 ? 1 : c->scheduler;
     // the pool kernel's parked records hold the bounce number in 11 bits
@@ -575,6 +576,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 return r;
             }
         }
+    } else if (c->jit == 2) {
+        return fail(RTPBR_ESTATE, "option jit = 2 (strict): no run-time instance exists for this scene (needs <= 8 analytic shapes, "
+                                  "or the neural shape with jit_bake, and the pool scheduler)");
     }
     pack_objects(c, P);
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
@@ -796,7 +800,7 @@ extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
     return RTPBR_OK;
 }
 
-// Named counters of the last rtpbr_sample() call: the six of rtpbr_counters plus "mlp_wave_evals" (passes of the
+// Named counters of the last rtpbr_sample() call: the six of rtpbr_counters plus "mlp_wave_evals" (32-ray half passes of the
 // wave-cooperative neural-SDF MLP) and "mlp_lane_evals" (ray evaluations those passes were needed for).
 extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long long* out) {
     if (!c || !name || !out) return fail(RTPBR_EINVAL, "null argument");
@@ -892,6 +896,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "mlp_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "mlp_lanes must be 1..64");
         c->mlp_lanes = (int)value;
+    } else if (!strcmp(key, "mlp_full")) {
+        if (value < 1 || value > 65) return fail(RTPBR_EINVAL, "mlp_full must be 1..65 (65 = never compute both halves at once)");
+        c->mlp_full = (int)value;
     } else if (!strcmp(key, "swap_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 1..64");
         c->swap_lanes = (int)value;

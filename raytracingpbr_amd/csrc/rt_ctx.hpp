@@ -104,7 +104,8 @@ struct rtpbr_ctx {
     int wait_lanes = 24;
     int shade_lanes = 56;
     int swap_lanes = 8;
-    int mlp_lanes = 16;
+    int mlp_lanes = 24;
+    int mlp_full = 56;
     int mlp_mfma = 1;
     int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
     int waves_per_cu = 0;  // 0 = from the occupancy query

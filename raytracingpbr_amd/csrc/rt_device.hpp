@@ -48,7 +48,7 @@ typedef const __attribute__((address_space(4))) f16v* CF16Ptr;
 // because a neuron's 16-term sum is one fma chain in the order (i outer, m inner) — see bunny_mlp_wave.
 constexpr float INV_1_4 = 0.714285731f;   // f32(1/1.4): the reference's "/ 1.4" (bunny_sdf_glass.py:190-193) as a multiplication
 
-// one 16 -> 16 layer: out[k*4+j] = act(chain_{i,m} in[m*4+i]*M_{k,m}[i][j] + b_k[j]) (*1/1.4) + in[k*4+j]
+// one 16 -> 16 layer: out[k*4+j] = sin(b_k[j] + chain_{i,m} in[m*4+i]*M_{k,m}[i][j]) (*1/1.4, fused) + in[k*4+j]
 template <bool DIV>
 RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
     // block b = k*4 + i (16 dwords [m][j]) lives at lw + k*68 + i*16
@@ -58,6 +58,7 @@ RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float acc[4];
+        CFloatPtr bias = lw + k * 68 + 64;      // the chain starts from the bias
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int b = k * 4 + i;
@@ -70,18 +71,16 @@ RT_D void bunny_layer(CFloatPtr lw, const float* in, float* out) {
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++) {
                     const float x = in[m * 4 + i];
-                    acc[jj] = fma_(x, w0[m * 4 + jj], (m == 0 && i == 0) ? 0.0f : acc[jj]);
+                    acc[jj] = fma_(x, w0[m * 4 + jj], (m == 0 && i == 0) ? bias[jj] : acc[jj]);
                 }
             }
             w0 = w1;
             w1 = w2;
         }
-        CFloatPtr bias = lw + k * 68 + 64;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
-            float sn = sin_pi_(acc[jj] + bias[jj]);
-            if (DIV) sn = sn * INV_1_4;
-            out[k * 4 + jj] = sn + in[k * 4 + jj];
+            const float sn = sin_pi_(acc[jj]);
+            out[k * 4 + jj] = DIV ? fma_(sn, INV_1_4, in[k * 4 + jj]) : sn + in[k * 4 + jj];
         }
     }
 }
@@ -119,11 +118,11 @@ RT_D float bunny_mlp(const float* __restrict__ wg, vec3 p) {
 // D[i = 4*(l>>4) + v][j = l&15] — then IS the next layer's B operand: instruction kb of the next layer takes
 // register v = kb, i.e. lane group g contributes neuron 4g + kb as its k-th term.  No LDS round trip, no
 // transposition between layers; the price is the summation order (kb outer, g inner) = (i outer, m inner) in
-// the reference's (block m, row i) indexing; the CPU checker uses the same order.  Residual adds and
-// biases stay in the same registers.  Only the 3 input coordinates (ray -> lane group) and the 16 outputs per
-// ray (lane group -> ray) cross lanes, through a 4 KB wave-private LDS buffer.
-// The 64 rays are processed as two halves of 2 x 16 rays: two independent chains interleave (MFMA of one block
-// under the sines of the other) with 8 + 8 live activation / accumulator registers instead of 16 + 16.
+// the reference's (block m, row i) indexing; the CPU checker uses the same order.  A layer's bias
+// is the C operand of its first MFMA (the chain starts from the bias), residual adds stay in the same registers.
+// Only the 3 input coordinates (ray -> slot's lane group) and the 16 outputs per ray (lane group -> ray) cross lanes,
+// through a 4 KB wave-private LDS buffer.  The 64 slots are processed as two halves of 2 x 16 rays (8 + 8 live
+// activation / accumulator registers instead of 16 + 16); callers compact their rays so that often one half suffices.
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int BUNNY_LDS_WORDS = 64 * 16;      // output staging [ray][16]; the input staging [3][64] aliases its upper half
 constexpr int BUNNY_LDS_IN = 512;
@@ -166,65 +165,71 @@ RT_D f4v mfma4(float, float, f4v c) { return c; }
 RT_D void bunny_lds_fence() {}
 #endif
 
-// MUST be called by all 64 lanes (wave-uniform control flow).  lp = this lane's local point (garbage allowed for
-// lanes that do not need a result: rays are independent).  Returns the MLP value for this lane's point.
-RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, float* lds, const float* bias_lds, int lane, vec3 lp) {
+// MUST be called by all 64 lanes (wave-uniform control flow).  lp = this lane's local point; `slot` = the ray slot
+// (0 .. 32*halves-1) this lane's point is evaluated in, or -1 when the lane has no point (slots nobody writes hold
+// stale values: rays are independent).  `halves` (1 or 2, wave-uniform) = how many 32-slot halves are computed:
+// the callers COMPACT the lanes that need a value into the low slots, so a pass costs what its rays need in units of
+// 32, not always 64.  Returns the MLP value of this lane's point (garbage for slot < 0).
+RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, float* lds, const float* bias_lds, int lane, vec3 lp,
+                          int slot, int halves) {
     const int io = lane & 15, g = lane >> 4;
     float* in = lds + BUNNY_LDS_IN;
-    in[0 * 64 + lane] = lp.y;
-    in[1 * 64 + lane] = lp.z;
-    in[2 * 64 + lane] = -lp.x;
+    if (slot >= 0) {
+        in[0 * 64 + slot] = lp.y;
+        in[1 * 64 + slot] = lp.z;
+        in[2 * 64 + slot] = -lp.x;
+    }
     bunny_lds_fence();
     const f4v bias1 = *reinterpret_cast<const f4v*>(&bias_lds[4 * g]);
     const f4v bias2 = *reinterpret_cast<const f4v*>(&bias_lds[16 + 4 * g]);
-    // Software pipeline over the two ray blocks of a half: while block A's four dependent MFMAs of a layer are in
-    // flight (each waits ~36 cycles for the previous one's accumulator), block B's four sines of the previous layer
-    // issue on the VALU — one sine (11 instructions) per MFMA, pinned with scheduling barriers.  A wave then keeps
-    // both pipes busy by itself instead of alternating MFMA-only and VALU-only phases.
+    // Two ray blocks per half.  The f32 matrix instructions do NOT overlap with VALU work on this chip — neither from
+    // the same wave nor from the other waves of the SIMD (tools/ubench/mfma_overlap.hip: 8 MFMA + 96 fma cost 510
+    // cycles back to back, 262 + 248 alone, and 604 when interleaved one MFMA : one sine) — so a layer is issued as
+    // one uninterrupted run of MFMAs (two dependent chains of four, back to back) followed by one run of sines,
+    // pinned with scheduling barriers; interleaving them costs 16 %.
 #pragma nounroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < halves; h++) {
         const f4v z = {0.0f, 0.0f, 0.0f, 0.0f};
         f4v act0, act1, c0, c1;
         {   // input layer: (p.y, p.z, -p.x, 1) . (wy, wz, wx, b); lane group g supplies component g of ray io
             const float x0 = in[(g < 3 ? g : 0) * 64 + (2 * h) * 16 + io];
             const float x1 = in[(g < 3 ? g : 0) * 64 + (2 * h + 1) * 16 + io];
+            RT_SCHED_BARRIER();
             c0 = mfma4(F.a0, g < 3 ? x0 : 1.0f, z);
             c1 = mfma4(F.a0, g < 3 ? x1 : 1.0f, z);
         }
         RT_SCHED_BARRIER();
 #pragma unroll
-        for (int v = 0; v < 4; v++) act0[v] = sin_pi_(c0[v]);
+        for (int v = 0; v < 4; v++) {
+            act0[v] = sin_pi_(c0[v]);
+            act1[v] = sin_pi_(c1[v]);
+        }
         RT_SCHED_BARRIER();
-        c0 = z;
+        c0 = mfma4(F.a1[0], act0[0], bias1);                                     // layer 1: the bias is the C operand
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) {          // layer 1 of block 0 || input sines of block 1
-            c0 = mfma4(F.a1[kb], act0[kb], c0);
-            act1[kb] = sin_pi_(c1[kb]);
-            RT_SCHED_BARRIER();
+        for (int kb = 1; kb < 4; kb++) c0 = mfma4(F.a1[kb], act0[kb], c0);
+        c1 = mfma4(F.a1[0], act1[0], bias1);
+#pragma unroll
+        for (int kb = 1; kb < 4; kb++) c1 = mfma4(F.a1[kb], act1[kb], c1);
+        RT_SCHED_BARRIER();
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            act0[v] = sin_pi_(c0[v]) + act0[v];
+            act1[v] = sin_pi_(c1[v]) + act1[v];
         }
-        c1 = z;
+        RT_SCHED_BARRIER();
+        c0 = mfma4(F.a2[0], act0[0], bias2);                                     // layer 2
 #pragma unroll
-        for (int kb = 0; kb < 4; kb++) {          // layer 1 of block 1 || layer-1 sines of block 0
-            c1 = mfma4(F.a1[kb], act1[kb], c1);
-            act0[kb] = sin_pi_(c0[kb] + bias1[kb]) + act0[kb];
-            RT_SCHED_BARRIER();
+        for (int kb = 1; kb < 4; kb++) c0 = mfma4(F.a2[kb], act0[kb], c0);
+        c1 = mfma4(F.a2[0], act1[0], bias2);
+#pragma unroll
+        for (int kb = 1; kb < 4; kb++) c1 = mfma4(F.a2[kb], act1[kb], c1);
+        RT_SCHED_BARRIER();
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            act0[v] = fma_(sin_pi_(c0[v]), INV_1_4, act0[v]);
+            act1[v] = fma_(sin_pi_(c1[v]), INV_1_4, act1[v]);
         }
-        c0 = z;
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++) {          // layer 2 of block 0 || layer-1 sines of block 1
-            c0 = mfma4(F.a2[kb], act0[kb], c0);
-            act1[kb] = sin_pi_(c1[kb] + bias1[kb]) + act1[kb];
-            RT_SCHED_BARRIER();
-        }
-        c1 = z;
-#pragma unroll
-        for (int kb = 0; kb < 4; kb++) {          // layer 2 of block 1 || layer-2 sines of block 0
-            c1 = mfma4(F.a2[kb], act1[kb], c1);
-            act0[kb] = sin_pi_(c0[kb] + bias2[kb]) * INV_1_4 + act0[kb];
-            RT_SCHED_BARRIER();
-        }
-#pragma unroll
-        for (int v = 0; v < 4; v++) act1[v] = sin_pi_(c1[v] + bias2[v]) * INV_1_4 + act1[v];
         // ---- back to lane = ray: [ray][neuron 4g .. 4g+3]
         *reinterpret_cast<f4v*>(&lds[((2 * h) * 16 + io) * 16 + 4 * g]) = act0;
         *reinterpret_cast<f4v*>(&lds[((2 * h + 1) * 16 + io) * 16 + 4 * g]) = act1;
@@ -233,7 +238,7 @@ RT_D float bunny_mlp_wave(const BunnyFrag& F, const float* __restrict__ wg, floa
     CFloatPtr ow = (CFloatPtr)wg + 64 + 544;
     f4v o[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) o[q] = *reinterpret_cast<const f4v*>(&lds[lane * 16 + 4 * q]);
+    for (int q = 0; q < 4; q++) o[q] = *reinterpret_cast<const f4v*>(&lds[(slot >= 0 ? slot : lane) * 16 + 4 * q]);
     bunny_lds_fence();    // the buffer is rewritten by the next call
     float sd = o[0][0] * ow[0];
 #pragma unroll
@@ -757,13 +762,15 @@ RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, con
     float d4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const int n_batches = (n_hit + 15) >> 4;
     for (int b = 0; b < n_batches; b++) {
+        const int halves = (n_hit - b * 16) > 8 ? 2 : 1;      // a last batch of <= 8 hits fills 32 slots only
         const int hidx = b * 16 + (lane >> 2);
         const int src = (int)tbl[hidx < n_hit ? hidx : 0];
         const vec3 hp = mk(__shfl(p.x, src, 64), __shfl(p.y, src, 64), __shfl(p.z, src, 64));
         const vec3 q = world ? hp : to_local<KIND_BUNNY>(P, o, hp);
         const vec3 l = world ? to_local<KIND_BUNNY>(P, o, q + e) : q + e * h;
         const float len = length(l);
-        const float sd = bunny_mlp_wave(F, P.bunny, lds, bias_lds, lane, l);
+        const float sd = bunny_mlp_wave(F, P.bunny, lds, bias_lds, lane, l, lane < 32 * halves ? lane : -1, halves);
+        n_passes += (uint32_t)halves;
         const float d = (len > 1.0f) ? len - 0.8f : sd;
         const bool mine = hit && (rank >> 4) == b;
 #pragma unroll
@@ -772,7 +779,6 @@ RT_D vec3 bunny_normal_wave(const Params& P, const BunnyFrag& F, float* lds, con
             d4[k] = mine ? v : d4[k];
         }
     }
-    n_passes += (uint32_t)n_batches;
     vec3 n = mk(0, 0, 0);
 #pragma unroll
     for (int k = 0; k < 4; k++) {

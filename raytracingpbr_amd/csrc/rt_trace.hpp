@@ -503,8 +503,6 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     uint32_t w_mlp_wave = 0, w_mlp_lane = 0;
     WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;   // slot masks (wave-uniform)
-    bool b_pending = false;                         // bunny: position evaluated, MLP still to run
-    vec3 b_lp = mk(0, 0, 0);
     __shared__ __attribute__((aligned(16))) float b_lds_all[(KIND == KIND_BUNNY) ? 4 * BUNNY_LDS_WORDS : 4];
     __shared__ __attribute__((aligned(16))) float b_bias[32];
     float* b_lds = &b_lds_all[(KIND == KIND_BUNNY) ? wave * BUNNY_LDS_WORDS : 0];
@@ -680,6 +678,10 @@ RT_D void trace_paths_pool_impl(const Params& P) {
             }
             const int n_ready = __popcll(m_ready);
             int n_done;
+            // bunny: position evaluated (local point b_lp), MLP still to run.  Lanes still waiting when the march phase
+            // is left re-derive their point on re-entry (the cheap half of the step; nothing has been counted yet)
+            bool b_pending = false;
+            vec3 b_lp = mk(0, 0, 0);
             do {
                 if (KIND == KIND_BUNNY) {
                     // The neural SDF costs ~1700 instructions, the bounding-sphere branch ~40.  Lanes outside
@@ -696,12 +698,22 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                         }
                         if (__popcll(__ballot(b_pending)) >= P.mlp_lanes) break;
                     }
-                    if (__any(b_pending)) {
-                        // all 64 lanes evaluate together on the matrix cores (uniform control flow)
-                        w_mlp_wave += 1u;
-                        w_mlp_lane += (uint32_t)__popcll(__ballot(b_pending));
-                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp);
-                        if (b_pending) {
+                    const unsigned long long pm = __ballot(b_pending);
+                    if (pm) {
+                        // The waiting lanes are COMPACTED into the low ray slots and the matrix cores compute whole
+                        // halves of 32 slots: all of them when >= mlp_full wait (two halves), else the first 32 by
+                        // rank — from the bottom and from the top of the wave in turn, so nobody starves; the others
+                        // keep waiting (they cost nothing) and join the next pass.  Uniform control flow.
+                        const int n_pend = __popcll(pm);
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+                        const int halves = n_pend >= P.mlp_full ? 2 : 1;
+                        const int take = n_pend < 32 * halves ? n_pend : 32 * halves;
+                        const int first = (w_mlp_wave & 1u) ? n_pend - take : 0;
+                        const bool sel = b_pending && rank >= first && rank < first + take;
+                        w_mlp_wave += (uint32_t)halves;
+                        w_mlp_lane += (uint32_t)take;
+                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp, sel ? rank - first : -1, halves);
+                        if (sel) {
                             march_update(P, L, 0, bunny_post_value(P, sd));
                             b_pending = false;
                         }

@@ -124,6 +124,7 @@ struct Params {
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)
+    int32_t mlp_full;       // bunny: compute both 32-slot halves when at least this many wait, else the first 32
     // pointers
     float4* stage;
     float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel

@@ -146,10 +146,21 @@ def test_fuzzed_scenes_through_run_time_instances(seed, tmp_path, monkeypatch):
     monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     sc, cfg, env, n = random_case(100 + seed) if seed % 2 else random_box8_case(100 + seed)
     analytic = all(ob.type != SHAPE.BUNNY for ob in sc.objects)
-    if cfg.kernel_form != 0 or len(sc.objects) > 8 or not analytic:
-        pytest.skip("complete-path scenes of <= 8 analytic shapes only")
+    eligible = len(sc.objects) <= 8 and analytic
     o = run(OracleRenderer(sc, cfg), env, n, False)
     g = Renderer(sc, cfg)
+    if not eligible:
+        # more than 8 objects, or the neural shape without baking: "jit" = 1 must fall back to the ahead-of-time kernels
+        # silently and give the same bits; "jit" = 2 (strict) must refuse
+        g.set_option("jit", 1)
+        g = run(g, env, n, False)
+        assert g.counter("jit_active") == 0
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+        s = Renderer(sc, cfg)
+        s.set_option("jit", 2)
+        with pytest.raises(Exception):
+            run(s, env, n, False)
+        return
     g.set_option("jit", 2)
     g.set_option("jit_bake", seed // 2 % 2)
     if seed % 4 < 2:

@@ -32,7 +32,7 @@ out = []
 for opts, b, r in zip(variants, best, rs):
     c = r.counters(); we, le = r.counter("mlp_wave_evals"), r.counter("mlp_lane_evals")
     rec = dict(opts=opts, ms=round(b, 2), Msamples_per_s=round(1920 * 1080 * spp / b / 1e3, 1), mlp_wave_evals_per_sample=round(we / c.samples, 4),
-               mlp_lane_evals_per_sample=round(le / c.samples, 3), mlp_lane_utilisation=round(le / max(we * 64, 1), 4),
+               mlp_lane_evals_per_sample=round(le / c.samples, 3), mlp_lane_utilisation=round(le / max(we * 32, 1), 4),
                raycasts_per_sample=round(c.raycasts / c.samples, 3), steps_per_raycast=round(c.march_steps / c.raycasts, 2))
     out.append(rec); print(json.dumps(rec), flush=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "bunny.json"), "w"), indent=1)

@@ -16,7 +16,12 @@ if not fs: print("no output, see pmcc_$i.err"); raise SystemExit
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(fs[0])):
     k = r["Kernel_Name"]
-    if "trace_paths" in k or "primary" in k: acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+    if any(t in k for t in ("trace_paths", "primary", "rt_jit", "persistent")): acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in acc.items(): print(k[:44], {c: "%.4g" % x for c, x in v.items()})
+import json, os
+path = "$OUT/pmc_cfg_$CFG.json"
+old = json.load(open(path)) if os.path.exists(path) and $i > 1 else {}
+for k, v in acc.items(): old.setdefault(k.split("(")[0][:60], {}).update(v)
+json.dump(old, open(path, "w"), indent=1)
 PY
 done

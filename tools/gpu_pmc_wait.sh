@@ -16,7 +16,7 @@ if not fs: print("no output for set $i; see pmcw_$i.err"); raise SystemExit
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
 for r in csv.DictReader(open(fs[0])):
     k = r["Kernel_Name"]
-    if "trace_paths" in k or "primary" in k:
+    if any(t in k for t in ("trace_paths", "primary", "rt_jit", "persistent")):
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k, v in acc.items():
     print(k[:40], {c: "%.4g" % (x / n[(k, c)]) for c, x in v.items()})
