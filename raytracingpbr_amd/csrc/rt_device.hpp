@@ -562,6 +562,7 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
     asm volatile("" : "+s"(tab));
     const float eps = 1.9073486328125e-06f * (fabs_(t) + P.cull_extent);
     const float bound = ub + eps;
+    const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
     best = P.cfg.max_dis;   // the reference starts from object 0 or from MAX_DIS (nearest_init); see below
     idx = 0;
     bool first = !P.cfg.nearest_init;
@@ -570,7 +571,9 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
         if constexpr (SIG == 0) {
             if (i >= P.n_obj) return;
         }
-        if (__all(!active || lb[i] > bound)) return;              // provably not the nearest for any lane
+        // provably not the nearest for any lane: skip.  (v_cmp straight into a scalar mask: 13 = "unordered or <=", i.e.
+        // !(lb > bound); __all / __ballot cost two more VALU instructions per object here)
+        if ((__builtin_amdgcn_fcmpf(lb[i], bound, 13) & act_mask) == 0ull) return;
         const ObjM o = load_obj<SIG, i>(tab);
         float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i), jit_type(i)));
         lb[i] = d - eps;

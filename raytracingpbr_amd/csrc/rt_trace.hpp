@@ -731,10 +731,10 @@ RT_D void trace_paths_pool_impl(const Params& P) {
         RT_PHASE(tA)
     }
 #ifdef RT_DEBUG_PHASE
-    if (lane == 0) {   // DEBUG: cycles per phase, summed over waves, in the hits / sky / deposits counters
-        atomicAdd(&P.counters->hits, tB >> 10);
+    if (lane == 0) {   // DEBUG: cycles per phase >> 10, summed over waves, in the mlp_wave / sky / mlp_lane counters (scenes without sky or MLP)
+        atomicAdd(&P.counters->mlp_wave_evals, tB >> 10);
         atomicAdd(&P.counters->sky_lookups, tD >> 10);
-        atomicAdd(&P.counters->deposits, tA >> 10);
+        atomicAdd(&P.counters->mlp_lane_evals, tA >> 10);
     }
 #endif
     if (KIND == KIND_BUNNY && lane == 0 && w_mlp_wave) {

@@ -6,7 +6,6 @@ W, H = 1920, 1080
 r = Renderer(cornell_box("v3", aspect=W / H), Config.cornell_v3(W, H, 0, 8))
 r.sample(64); r.sync()
 r.refresh(); r.sample(64); c = r.counters(); tr, tot, n = r.last_sample_ms()
-B, D, A = c.hits, c.sky_lookups, c.deposits - W * H * 64
-# hits/sky include the real counts (small next to cycles>>10? no: subtract nothing, report raw and shares)
+B, D, A = r.counter("mlp_wave_evals"), c.sky_lookups, r.counter("mlp_lane_evals")
 t = B + D + A
 print("trace ms", tr, "phase shares (cycle sums >> 10): shade/refill B %.3f  dispatch %.3f  march A %.3f" % (B / t, D / t, A / t), B, D, A)
