@@ -164,6 +164,31 @@ def test_schedule_independence():
     assert np.all(r.image_buffer[..., 3] == 12.0)
 
 
+def test_neural_sdf_pass_policy_independence():
+    """The neural SDF is evaluated wave-cooperatively: waiting rays are compacted into 32-slot half passes and which
+    rays a pass takes depends on the policy options.  Every policy — and the VALU-only network — must give the
+    oracle's bits, the same number of network evaluations, and never more slots than 32 per half pass."""
+    case = case_by_name("bunny_glass")
+    o = OracleRenderer(case.scene, case.cfg)
+    case.run(o)
+    want = bits(o.image_buffer)
+    evals = o.counter("mlp_lane_evals")
+    assert evals > 0
+    for opts in ({}, {"mlp_lanes": 1, "mlp_full": 1}, {"mlp_lanes": 1, "mlp_full": 65}, {"mlp_lanes": 64, "mlp_full": 64},
+                 {"mlp_lanes": 33, "mlp_full": 34}, {"mlp_lanes": 16, "mlp_full": 48, "shade_lanes": 5, "swap_lanes": 3},
+                 {"mlp_lanes": 40, "mlp_full": 60, "waves_per_cu": 4}, {"mlp_mfma": 0}, {"jit": 2, "jit_bake": 1, "mlp_lanes": 7}):
+        r = Renderer(case.scene, case.cfg)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        case.run(r)
+        assert np.array_equal(bits(r.image_buffer), want), opts
+        if opts.get("mlp_mfma", 1):
+            halves = r.counter("mlp_wave_evals")
+            assert r.counter("mlp_lane_evals") == evals, opts
+            assert evals <= 32 * halves, opts
+        r.close()
+
+
 @pytest.mark.parametrize("rots", ["axis_aligned", "mixed_axes", "tilted"])
 def test_rotation_signatures_match_oracle(rots):
     """8-box scenes whose rotation signature fits / does not fit the ahead-of-time specialised
