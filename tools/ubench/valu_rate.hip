@@ -11,6 +11,9 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 1e-3f + i;
     float b = seed * 0.5f, c = seed * 0.25f;
+    double d[8], db = seed * 0.5, dc = seed * 0.25;      // VGPR pairs for the packed-f32 instructions
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = seed + threadIdx.x * 1e-3 + i;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -59,7 +62,9 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
                 if (KIND == 40) asm volatile("v_sub_f32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "+v"(a[i]) : "v"(b));
                 if (KIND == 41) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (KIND == 42) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
-                if (KIND == 43) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*(double*)&a[i & 6]) : "v"(*(double*)&a[(i & 6)]));
+                if (KIND == 43) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(d[i]) : "v"(db));
+                if (KIND == 46) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[i]) : "v"(db), "v"(dc));
+                if (KIND == 47) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(d[i]) : "v"(db));
                 if (KIND == 44) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (KIND == 45) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[i]));
             }
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
     }
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s += a[i];
+    for (int i = 0; i < 8; i++) s += a[i] + (float)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -103,6 +108,7 @@ int main() {
         run<32>("v_subrev_f32_dpp newbcast", w); run<33>("v_mul_f32_dpp newbcast", w); run<34>("v_fmac_f32_dpp newbcast", w);
         run<35>("v_subrev_dpp newbcast |abs|", w); run<36>("v_add_f32_e64 v,|v|", w); run<37>("v_min_f32", w); run<38>("v_mov_b32_dpp newbcast", w);
         run<39>("v_subrev_dpp quad_perm", w); run<40>("v_sub_f32_sdwa", w); run<41>("v_and_b32", w); run<42>("v_add_u32", w); run<44>("v_xor_b32", w); run<45>("v_lshlrev_b32", w);
+        run<43>("v_pk_mul_f32 (2 x f32)", w); run<46>("v_pk_fma_f32 (2 x f32)", w); run<47>("v_pk_add_f32 (2 x f32)", w);
     }
     return 0;
 }
