@@ -448,7 +448,7 @@ RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
         float s2 = dot(u, u);
         float t = fma_(mx, -2.0f, four_rho);
         const bool out = mx > 0.0f;
-        has_core = has_core || !out;
+        has_core = has_core | !out;
         float key = out ? s2 : t * t;
         bool lt = key < k1;
         k3 = __builtin_amdgcn_fmed3f(key, k2, k3);   // k1 <= k2 <= k3 always: medians insert the new key
@@ -629,7 +629,8 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
         bool fb = (!P.cfg.omega_guard || L.w > 1.0f) && (ld + dist < L.s);
         // fallback branch: s -= w*s; t += s; w = a + b*w; continue
         float s_fb = L.s - L.w * L.s;
-        float w_fb = P.cfg.omega_fb_a + P.cfg.omega_fb_b * L.w;
+        // (omega_fb_b == 0: w is finite and positive, so a + 0*w == a exactly; saves the two instructions a baked 0 cannot fold)
+        float w_fb = P.cfg.omega_fb_b == 0.0f ? P.cfg.omega_fb_a : P.cfg.omega_fb_a + P.cfg.omega_fb_b * L.w;
         // normal branch: err = d / t; hit = err < PIXEL_RADIUS.  The correctly rounded quotient
         // is only needed when d is within 2^-20 (relative) of t*eps; otherwise the comparison is
         // decided by the product (monotone rounding), which saves the 11-instruction divide on
@@ -648,10 +649,12 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
         L.s = s_new;
         L.t += s_new;
         L.w = fb ? w_fb : L.w;
-        hit = !fb && hit_n;
-        done = !fb && (hit || L.t > P.cfg.max_dis);
+        // (bitwise on purpose: keeps the lane masks in scalar registers instead of 0/1 selects in VGPRs)
+        const bool nfb = !fb;
+        hit = nfb & hit_n;
+        done = nfb & (hit_n | (L.t > P.cfg.max_dis));
     }
-    done = done || (L.steps_left == 0);
+    done = done | (L.steps_left == 0);
     if (done) L.state = hit ? ST_HIT : ST_MISS;
 }
 

@@ -8,10 +8,12 @@ from raytracingpbr_amd import SHAPE, Config, Renderer, bunny, cornell_box, src_s
 from raytracingpbr_amd.ibl import load_bunny_weights, synthetic_env
 from raytracingpbr_amd.tiles import default_tile
 
-only = set(sys.argv[1:])
+LIST = "--list" in sys.argv          # print the config names (one per line) and exit
+only = set(a for a in sys.argv[1:] if a != "--list")
 res = {}
 
 def run(name, sc, cfg, spp, env=None, envexp=1.8, tiles=None, chunk=None, warm=1):
+    if LIST: print(name); return
     if only and name not in only: return
     r = Renderer(sc, cfg)
     if env is not None: r.set_env(env, envexp, 2.2)
@@ -44,4 +46,8 @@ tw, th = default_tile(7680, 4320, 8)
 spp5 = int(os.environ.get("C5_SPP", "4096"))
 run(f"C5_cornell_8k_{spp5}spp_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), spp5, tiles=(tw, th, 0, 8), chunk=256)
 run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4, chunk=64)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w"), indent=1)
+if not LIST:
+    path = os.path.join(ROOT, "gpurun_out", "configs.json")
+    if only and os.path.exists(path):            # per-config invocations accumulate into one file
+        old = json.load(open(path)); old.update(res); res = old
+    json.dump(res, open(path, "w"), indent=1)

@@ -9,29 +9,38 @@ import sys
 tag = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-lines = [f"== rocprofv3 --kernel-trace --stats -- python tools/gpu_configs.py   (tag {tag}; C3_SPP/C5_SPP as in tools/gpu_round2.sh)"]
-f = glob.glob(os.path.join(OUT, f"prof_cfg_{tag}", "**", "*kernel_stats.csv"), recursive=True)
-summary = {"tag": tag}
-if f:
-    lines.append(f"{'kernel':78s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>10s} {'pct':>7s}")
-    ks = []
-    for r in csv.DictReader(open(f[0])):
-        name = r.get("Name", "?")
-        ks.append({"kernel": name, "calls": int(r.get("Calls", 0)), "total_ms": float(r.get("TotalDurationNs", 0)) / 1e6,
-                   "avg_ms": float(r.get("AverageNs", 0)) / 1e6, "pct": float(r.get("Percentage", 0))})
-        lines.append(f"{name[:78]:78s} {ks[-1]['calls']:6d} {ks[-1]['total_ms']:12.3f} {ks[-1]['avg_ms']:10.4f} {ks[-1]['pct']:7.2f}")
-    summary["kernel_stats"] = ks
-f = glob.glob(os.path.join(OUT, f"prof_cfg_{tag}", "**", "*kernel_trace.csv"), recursive=True)
-if f:
-    seen = {}
-    for r in csv.DictReader(open(f[0])):
-        n = r.get("Kernel_Name", "?")
-        if n not in seen:
-            seen[n] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
-    lines.append("\n== per-kernel resources (first dispatch)")
-    for n, v in seen.items():
-        lines.append(f"{n[:78]:78s} {v}")
-    summary["resources"] = seen
+lines = [f"== rocprofv3 --kernel-trace --stats -- python tools/gpu_configs.py <config>   (tag {tag}; one run per config: the run-time "
+         f"compiled kernels of every scene carry the same names; C3_SPP/C5_SPP as in tools/gpu_round2.sh)"]
+summary = {"tag": tag, "per_config": {}}
+base = os.path.join(OUT, f"prof_cfg_{tag}")
+for cfg in sorted(os.listdir(base)) if os.path.isdir(base) else []:
+    d = os.path.join(base, cfg)
+    if not os.path.isdir(d):
+        continue
+    entry = {}
+    f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    lines.append(f"\n-- {cfg}")
+    if f:
+        lines.append(f"{'kernel':78s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>10s} {'pct':>7s}")
+        ks = []
+        for r in csv.DictReader(open(f[0])):
+            name = r.get("Name", "?")
+            ks.append({"kernel": name, "calls": int(r.get("Calls", 0)), "total_ms": float(r.get("TotalDurationNs", 0)) / 1e6,
+                       "avg_ms": float(r.get("AverageNs", 0)) / 1e6, "pct": float(r.get("Percentage", 0))})
+            if ks[-1]["pct"] >= 0.05:
+                lines.append(f"{name[:78]:78s} {ks[-1]['calls']:6d} {ks[-1]['total_ms']:12.3f} {ks[-1]['avg_ms']:10.4f} {ks[-1]['pct']:7.2f}")
+        entry["kernel_stats"] = ks
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if f:
+        seen = {}
+        for r in csv.DictReader(open(f[0])):
+            n = r.get("Kernel_Name", "?")
+            if n not in seen and not n.startswith("__amd"):
+                seen[n] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+        for n, v in seen.items():
+            lines.append(f"   resources {n[:60]:60s} {v}")
+        entry["resources"] = seen
+    summary["per_config"][cfg] = entry
 p = os.path.join(OUT, f"configs_{tag}.log")
 if os.path.exists(p):
     lines.append("\n== throughput lines printed by the run (device time from HIP events)")
