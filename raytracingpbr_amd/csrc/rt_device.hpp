@@ -635,9 +635,10 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
         // is only needed when d is within 2^-20 (relative) of t*eps; otherwise the comparison is
         // decided by the product (monotone rounding), which saves the 11-instruction divide on
         // practically every step.  Wave-uniform branch: taken if ANY active lane is in the band.
-        float te = L.t * P.cfg.hit_eps;
-        bool sure_hit = dist < te * 0.99999905f;
-        bool sure_miss = dist > te * 1.00000095f;
+        // (thresholds t * (eps (1 -+ 2^-20)): a conservative pre-filter, 16 ulp wide against two roundings; any
+        // lane inside the band sends the wave to the exact quotient, so the decision is the reference's either way)
+        bool sure_hit = dist < L.t * (P.cfg.hit_eps * 0.99999905f);
+        bool sure_miss = dist > L.t * (P.cfg.hit_eps * 1.00000095f);
         bool unsure = !(sure_hit || sure_miss) || !(L.t > 0.0f);
         bool hit_n = sure_hit;
         if (__any(unsure)) {
