@@ -14,7 +14,9 @@ for seed in range(lo, hi):
     sc, cfg, env, n = random_case(seed)
     o = run(OracleRenderer(sc, cfg), env, n, cfg.kernel_form == 1)
     co = o.counters()
-    for opts in ({}, {"primary_split": 2}):
+    variants = [{}, {"primary_split": 2}]
+    if seed % 3 == 0: variants.append({"jit": 1, "jit_bake": seed % 2})      # run-time instance where the scene is eligible
+    for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)
         g = run(g, env, n, cfg.kernel_form == 1)
