@@ -434,25 +434,28 @@ static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj
 // Staging (one float4 per item) and, for the primary split, the primary records (one float2 per item).
 // Grown on demand; hipMalloc of several GB takes 50..700 ms, so callers that time whole frames can
 // reserve up front (option "reserve_spp").
+// Returns RTPBR_ENOMEM (nothing allocated, no sticky HIP error) when the device has no room: the caller then renders
+// with fewer samples per launch instead of failing.
+static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
+    if (need <= *cap) return RTPBR_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    const hipError_t e = hipMalloc(ptr, need);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return RTPBR_ENOMEM;
+    }
+    if (e != hipSuccess) return rt_fail_hip("hipMalloc(staging)", e);
+    *cap = need;
+    return RTPBR_OK;
+}
 static int ensure_staging(rtpbr_ctx* c, size_t items, bool split) {
-    const size_t need = items * sizeof(float4);
-    if (need > c->stage_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->stage);
-        c->stage = nullptr;
-        c->stage_cap = 0;
-        HIP_TRY(hipMalloc(&c->stage, need));
-        c->stage_cap = need;
-    }
-    const size_t pneed = items * sizeof(float2);
-    if (split && pneed > c->primary_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(c->primary);
-        c->primary = nullptr;
-        c->primary_cap = 0;
-        HIP_TRY(hipMalloc(&c->primary, pneed));
-        c->primary_cap = pneed;
-    }
+    if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(float4))) return r;
+    if (split)
+        if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * sizeof(float2))) return r;
     return RTPBR_OK;
 }
 
@@ -646,7 +649,13 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             int K = (int)(left < kmax ? left : kmax);
             // the extra launch has a fixed cost of ~0.3 ms: below ~8 M items the fused kernel is faster
             const bool split = split_ok && (c->primary_split == 2 || (long long)P.np * K >= (1LL << 23));
-            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split)) return r;
+            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split)) {
+                // no room for K samples per launch: halve the budget and go round again (1 spp per launch must fit)
+                if (r != RTPBR_ENOMEM || K == 1)
+                    return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "no device memory for the staging of one sample per pixel") : r;
+                c->staging_bytes = (long long)((K + 1) / 2) * per_spp;
+                continue;
+            }
             P.primary = c->primary;
             P.primary_split = split ? 1 : 0;
             P.stage = c->stage;
@@ -921,7 +930,8 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (kmax > k32) kmax = k32;
         if (kmax < 1) kmax = 1;
         const long long K = value < kmax ? value : kmax;
-        if (int r = ensure_staging(c, (size_t)c->P.np * (size_t)K, split_ok)) return r;
+        if (int r = ensure_staging(c, (size_t)c->P.np * (size_t)K, split_ok))
+            return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "reserve_spp: no device memory for the staging of that many samples per pixel") : r;
     } else if (!strcmp(key, "sample_base")) {
         c->sample_base = (uint32_t)value;
     } else {

@@ -289,6 +289,31 @@ def test_refresh_semantics():
     assert np.array_equal(r.ray_buffer[..., :9], rb[..., :9])
 
 
+def test_staging_allocation_failure_falls_back_to_fewer_samples_per_launch():
+    """When the device cannot hold the staging of a whole call (one float4 per pixel-sample), the call must split itself
+    into smaller launches instead of failing — same bits."""
+    import torch
+    W, H, SPP = 1920, 1080, 64                                  # 64 spp: 2.1 GB of staging + 1.1 GB of primary records
+    sc, cfg = cornell_box("v3", aspect=W / H), Config.cornell_v3(W, H, 0, 8)
+    ref = Renderer(sc, cfg)
+    ref.sample(SPP)
+    want = bits(ref.image_buffer)
+    ref.close()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(free - (1500 << 20), dtype=torch.uint8, device="cuda")     # leave 1.5 GB
+    try:
+        r = Renderer(sc, cfg)
+        r.sample(SPP)
+        assert np.array_equal(bits(r.image_buffer), want)
+        tr, tot, launches = r.last_sample_ms()
+        assert launches >= 2                                     # it did split
+        r.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+
+
 def test_error_channel():
     api = hip_api()
     ctx = C.c_void_p()
