@@ -129,10 +129,11 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
     mkdirs(cdir);
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
-    const std::string tpath = path + tmp, log = path + ".log";
+    // everything this process writes carries its pid: ranks of one job build the same key at the same time
+    const std::string tpath = path + tmp, log = tpath + ".log";
     std::string table_def;
     if (key.baked) {
-        const std::string tfile = path + ".table.hpp";
+        const std::string tfile = tpath + ".table.hpp";
         FILE* f = fopen(tfile.c_str(), "w");
         if (!f) return rt_fail(RTPBR_ESTATE, "cannot write %s", tfile.c_str());
         fprintf(f, "// generated by rt_jit.hip: the scene's march table (ObjM blocks) as bit patterns\n");
@@ -182,6 +183,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
         return rt_fail(RTPBR_ESTATE, "cannot move the compiled code object into the cache (%s)", path.c_str());
     }
     unlink(log.c_str());
+    if (key.baked) unlink((tpath + ".table.hpp").c_str());
     *out = path;
     return RTPBR_OK;
 }

@@ -171,3 +171,39 @@ def test_fuzzed_scenes_through_run_time_instances(seed, tmp_path, monkeypatch):
     assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
     cg, co = g.counters(), o.counters()
     assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups) == (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups)
+
+
+_RANK_SCRIPT = r"""
+import sys, zlib
+import numpy as np
+sys.path[:0] = [{root!r}, {tests!r}]
+from cases import case_by_name
+from raytracingpbr_amd import Renderer
+case = case_by_name("cornell_v3_8b_wide")
+r = Renderer(case.scene, case.cfg)
+r.set_option("jit", 2)
+r.set_option("jit_bake", 1)
+r.set_tiles(8, 8, 0, 4)
+r.sample(5)
+assert r.counter("jit_active") == 1
+print("CRC", zlib.crc32(np.ascontiguousarray(r.image_buffer).tobytes()))
+"""
+
+
+def test_ranks_of_one_job_build_the_same_key_concurrently(tmp_path):
+    """bench.py under torchrun: every rank asks for the same baked key at the same moment, with an empty cache.  Each
+    process writes only pid-suffixed files and renames the code object into place, so all of them must succeed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTPBR_JIT_CACHE=str(tmp_path))
+    code = _RANK_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(4)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    crcs = {so.strip().splitlines()[-1] for so, _ in outs}
+    assert len(crcs) == 1
+    left = sorted(os.listdir(tmp_path))
+    assert len([f for f in left if f.endswith(".hsaco")]) == 1 and not [f for f in left if ".tmp." in f], left
