@@ -148,7 +148,6 @@ extern "C" int rtpbr_rccl_init_all(rtpbr_ctx** ctxs, int n) {
 // pack -> ncclGather -> (root) unpack, all on the context's stream
 static int enqueue_gather(rtpbr_ctx* c) {
     RT_HIP_TRY(hipSetDevice(c->device));
-    if (int r = ensure_gather_buffers(c)) return r;
     c->P.cfg = c->cfg;
     c->P.image_buffer = c->image_buffer;
     launch_pack(c->P, (float4*)c->gather_send, c->stream);
@@ -175,14 +174,19 @@ static int enqueue_unpack(rtpbr_ctx* c) {
 
 extern "C" int rtpbr_gather_tiles(rtpbr_ctx* c) {
     if (int r = check_comm(c)) return r;
+    RT_HIP_TRY(hipSetDevice(c->device));
+    if (int r = ensure_gather_buffers(c)) return r;
     if (int r = enqueue_gather(c)) return r;
     return enqueue_unpack(c);
 }
 
 extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
     if (!ctxs || n < 1) return rt_fail(RTPBR_EINVAL, "bad gather_tiles_all arguments");
-    for (int i = 0; i < n; i++)
+    for (int i = 0; i < n; i++) {
         if (int r = check_comm(ctxs[i])) return r;
+        RT_HIP_TRY(hipSetDevice(ctxs[i]->device));
+        if (int r = ensure_gather_buffers(ctxs[i])) return r;     // allocations and their syncs stay outside the group
+    }
     NCCL_TRY(g_rccl.GroupStart());
     int rc = RTPBR_OK;
     for (int i = 0; i < n && rc == RTPBR_OK; i++) rc = enqueue_gather(ctxs[i]);
