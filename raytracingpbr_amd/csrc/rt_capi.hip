@@ -504,6 +504,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.counters = c->counters;
     P.wait_lanes = c->wait_lanes;
     P.shade_lanes = c->shade_lanes;
+    P.refill_lanes = c->refill_lanes;
     P.swap_lanes = c->swap_lanes;
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_full = c->mlp_full;
@@ -882,6 +883,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "refill_lanes")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "refill_lanes must be 1..64");
+        c->refill_lanes = (int)value;
     } else if (!strcmp(key, "primary_split")) {
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "primary_split must be 0 (never), 1 (large launches) or 2 (always)");
         c->primary_split = (int)value;

@@ -103,6 +103,7 @@ struct rtpbr_ctx {
     long long staging_bytes = 16LL << 30;  // 288 GB of HBM: a whole 1080p x 256 spp step (8.5 GB of samples + 4.2 GB of primary records) is one launch
     int wait_lanes = 24;
     int shade_lanes = 56;
+    int refill_lanes = 24;
     int swap_lanes = 8;
     int mlp_lanes = 24;
     int mlp_full = 56;

@@ -520,6 +520,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
 
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter();
+    unsigned long long dbg_march_lanes = 0, dbg_march_steps = 0, dbg_shade_lanes = 0, dbg_shade_passes = 0;
 #define RT_PHASE(acc) { unsigned long long tn = __builtin_readcyclecounter(); acc += tn - tc; tc = tn; }
 #else
 #define RT_PHASE(acc)
@@ -587,8 +588,12 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                 if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col, 1.0f);
                 w_samples += (uint32_t)__popcll(__ballot((st == SL_HIT || st == SL_MISS) && !alive));
                 if (st == SL_HIT || st == SL_MISS) st = SL_EMPTY;
-                // refill free slots with fresh pixel-samples
-                bool got = claim_items(P, wr, st == SL_EMPTY && !alive, lane, R.item);
+                // refill free slots with fresh pixel-samples.  start_item costs ~200 instructions and a shading pass frees
+                // only about a third of its slots, so the refill may wait until refill_lanes slots are free — unless this
+                // pass was started because the pool ran dry
+                const bool is_free = st == SL_EMPTY && !alive;
+                const bool do_refill = __popcll(__ballot(is_free)) >= P.refill_lanes || n_shade < T;
+                bool got = claim_items(P, wr, is_free && do_refill, lane, R.item);
                 uint32_t resumed = 0;   // primary_split: state the primary kernel left this item in
                 bool roulette0 = false;
                 // the primary record is requested BEFORE the camera ray is regenerated: the ~150 instructions of
@@ -720,6 +725,10 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     }
                 } else {
                     w_steps += (uint32_t)n_march;
+#ifdef RT_DEBUG_PHASE
+                    dbg_march_lanes += (unsigned)n_march;
+                    dbg_march_steps += 1;
+#endif
                     if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
                 }
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -735,6 +744,8 @@ RT_D void trace_paths_pool_impl(const Params& P) {
         atomicAdd(&P.counters->mlp_wave_evals, tB >> 10);
         atomicAdd(&P.counters->sky_lookups, tD >> 10);
         atomicAdd(&P.counters->mlp_lane_evals, tA >> 10);
+        atomicAdd(&P.counters->hits, dbg_march_lanes);          // (replaces the hit count in this build)
+        atomicAdd(&P.counters->deposits, dbg_march_steps);
     }
 #endif
     if (KIND == KIND_BUNNY && lane == 0 && w_mlp_wave) {
@@ -743,7 +754,12 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     }
     // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
     flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
-                   lane == 0 ? w_hits : 0u, lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);
+#ifdef RT_DEBUG_PHASE
+                   0u,
+#else
+                   lane == 0 ? w_hits : 0u,
+#endif
+                   lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);
 }
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256, pool_waves(KIND)) trace_paths_pool(const Params P) { trace_paths_pool_impl<KIND, NOBJ, SIG>(P); }
