@@ -120,13 +120,25 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
     char name[256];
     snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
              key.cull, key.waves, (unsigned long long)th, (unsigned long long)sh);
-    const std::string cdir = cache_dir();
-    const std::string path = cdir + "/" + name + ".hsaco";
+    std::string cdir = cache_dir();
+    std::string path = cdir + "/" + name + ".hsaco";
     if (access(path.c_str(), R_OK) == 0) {
         *out = path;
         return RTPBR_OK;
     }
     mkdirs(cdir);
+    if (access(cdir.c_str(), W_OK) != 0 && !getenv("RTPBR_JIT_CACHE")) {
+        // read-only home directory: fall back to a per-user directory under /tmp rather than lose the specialisation
+        char alt[64];
+        snprintf(alt, sizeof alt, "/tmp/rtpbr-cache-%d", (int)getuid());
+        cdir = alt;
+        path = cdir + "/" + name + ".hsaco";
+        if (access(path.c_str(), R_OK) == 0) {
+            *out = path;
+            return RTPBR_OK;
+        }
+        mkdirs(cdir);
+    }
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
     // everything this process writes carries its pid: ranks of one job build the same key at the same time

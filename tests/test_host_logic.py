@@ -241,3 +241,23 @@ def test_run_time_instance_compiles_without_a_gpu(tmp_path, monkeypatch):
     monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
     lib.rtpbr_last_error.restype = C.c_char_p
     assert f(0, 3, 0x222, 0x49, 1, 5, buf, 512) != 0 and b"run-time compilation failed" in lib.rtpbr_last_error()
+
+
+def test_run_time_compilation_survives_an_unwritable_home(monkeypatch):
+    """A home directory the process cannot write to must not cost the specialised kernels: the cache falls back to a
+    per-user directory under /tmp (CPU-only: builds one code object)."""
+    import shutil
+    from raytracingpbr_amd import _capi
+    monkeypatch.delenv("RTPBR_JIT_CACHE", raising=False)
+    monkeypatch.delenv("XDG_CACHE_HOME", raising=False)
+    monkeypatch.setenv("HOME", "/proc/1/no-such-home")
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    f = lib.rtpbr_test_jit_build
+    f.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    lib.rtpbr_last_error.restype = C.c_char_p
+    buf = C.create_string_buffer(512)
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0, lib.rtpbr_last_error()
+    path = buf.value.decode()
+    want = "/tmp/rtpbr-cache-%d/" % os.getuid()
+    assert path.startswith(want) and os.path.getsize(path) > 10000
+    shutil.rmtree(want, ignore_errors=True)
