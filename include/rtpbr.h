@@ -323,7 +323,7 @@ int rtpbr_last_primary_ms(rtpbr_ctx* ctx, float* primary_ms, int* launches);
 int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
 /* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),
  * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
- * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes", "refill_lanes" (scheduler 1), "waves_per_cu",
+ * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes", "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
  * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
  * (default), 2 always), "specialize" (1: use the instance compiled

@@ -505,6 +505,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.wait_lanes = c->wait_lanes;
     P.shade_lanes = c->shade_lanes;
     P.refill_lanes = c->refill_lanes;
+    P.ready_low = c->ready_low;
     P.swap_lanes = c->swap_lanes;
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_full = c->mlp_full;
@@ -883,6 +884,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "ready_low")) {
+        if (value < 0 || value > 63) return fail(RTPBR_EINVAL, "ready_low must be 0..63");
+        c->ready_low = (int)value;
     } else if (!strcmp(key, "refill_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "refill_lanes must be 1..64");
         c->refill_lanes = (int)value;

@@ -104,6 +104,7 @@ struct rtpbr_ctx {
     int wait_lanes = 24;
     int shade_lanes = 56;
     int refill_lanes = 24;
+    int ready_low = 4;
     int swap_lanes = 8;
     int mlp_lanes = 24;
     int mlp_full = 56;

@@ -531,7 +531,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
             const int n_shade = __popcll(m_shade);
             const int n_ready = __popcll(m_ready);
             const int n_free = 64 - n_shade - n_ready;
-            const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && !wr.drained)));
+            const bool run_b = n_shade >= T || (n_ready <= P.ready_low && (n_shade > 0 || (n_free > 0 && !wr.drained)));
             if (run_b) {
                 // Shading needs ~60 registers of its own; the marching lanes' ray (origin, direction, relaxation
                 // state) is parked in LDS meanwhile instead of being spilled to scratch by the register cap

@@ -121,6 +121,7 @@ struct Params {
     int32_t wait_lanes;     // k*: leave the march phase when this many lanes wait for shading / a swap
     int32_t shade_lanes;    // pool scheduler: shade when this many parked rays wait
     int32_t refill_lanes;   // pool scheduler: start new pixel-samples when this many slots are free (or the pool runs dry)
+    int32_t ready_low;      // pool scheduler: also shade when no more than this many READY rays are parked
     int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU
