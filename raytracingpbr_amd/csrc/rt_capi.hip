@@ -668,7 +668,11 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             long long waves = (long long)grid * 4;
             long long chunk = (long long)P.total_items / (waves * 16);
             if (chunk < 64) chunk = 64;
-            if (chunk > 4096) chunk = 4096;
+            // A wave that claims the last chunk works it off 128 paths at a time while the others have drained: the tail
+            // is chunk / 128 path durations.  4096 cost 2 % on the Cornell frame and 18 % on the glass bunny (long paths);
+            // below ~2048 the curve is flat down to 256, and locality does not suffer (a chunk is still >= 4 pixels).
+            if (chunk > 1024) chunk = 1024;
+            if (c->chunk > 0) chunk = c->chunk;
             P.chunk = (uint32_t)chunk;
             HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
             if (split) {
@@ -884,6 +888,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "chunk")) {
+        if (value < 0 || value > (1 << 20)) return fail(RTPBR_EINVAL, "chunk must be 0 (automatic) .. 2^20");
+        c->chunk = (int)value;
     } else if (!strcmp(key, "ready_low")) {
         if (value < 0 || value > 63) return fail(RTPBR_EINVAL, "ready_low must be 0..63");
         c->ready_low = (int)value;
