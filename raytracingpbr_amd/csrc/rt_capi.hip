@@ -558,6 +558,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             key.cull = P.cull_ok;
             if (jit_bunny) key.sig = 0;
             key.waves = c->kind == KIND_BOXES ? 6 : c->kind == KIND_BUNNY ? 4 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
+            if (c->jit_waves > 0) key.waves = c->jit_waves;
             key.baked = c->jit_bake;
             key.table = reinterpret_cast<const unsigned*>(c->objm);
             if (key.baked) {
@@ -888,6 +889,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "shade_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "shade_lanes must be 1..64");
         c->shade_lanes = (int)value;
+    } else if (!strcmp(key, "jit_waves")) {
+        if (value < 0 || value > 8) return fail(RTPBR_EINVAL, "jit_waves must be 0 (default) .. 8");
+        c->jit_waves = (int)value;
     } else if (!strcmp(key, "chunk")) {
         if (value < 0 || value > (1 << 20)) return fail(RTPBR_EINVAL, "chunk must be 0 (automatic) .. 2^20");
         c->chunk = (int)value;

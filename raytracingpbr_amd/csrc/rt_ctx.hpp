@@ -105,6 +105,7 @@ struct rtpbr_ctx {
     int shade_lanes = 56;
     int refill_lanes = 24;
     int ready_low = 4;
+    int jit_waves = 0;            // waves per SIMD the run-time pool kernel is compiled for (0 = as the ahead-of-time instances)
     int chunk = 0;                // work items claimed per atomic by the pool kernels (0 = automatic)
     int swap_lanes = 8;
     int mlp_lanes = 24;

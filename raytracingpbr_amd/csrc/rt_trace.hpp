@@ -476,7 +476,9 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     __shared__ uint32_t pool_all[4][F_COUNT][64];
     constexpr bool PARK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
     __shared__ float save_all[PARK ? 4 : 1][PARK ? 7 : 1][PARK ? 64 : 1];   // marching state parked during shading
-    __shared__ uint32_t tbl_all[4][64];
+    // the swap's rank table (dispatch phase) shares its words with the parked marching state (shading phase) where that
+    // exists: never live together, and 1 KB less per block lets a seventh block fit into a CU's 160 KB
+    __shared__ uint32_t tbl_all[PARK ? 1 : 4][64];
     __shared__ uint32_t sstate_all[4][64];
     stage_objects(P, lds_obj);
 
@@ -484,7 +486,8 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     const int wave = threadIdx.x >> 6;
     uint32_t (*pool)[64] = pool_all[wave];
     uint32_t* sstate = sstate_all[wave];
-    const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
+    uint32_t* const tbl_w = PARK ? reinterpret_cast<uint32_t*>(&save_all[PARK ? wave : 0][0][0]) : tbl_all[PARK ? 0 : wave];
+    const PoolView V = {pool_all[wave], sstate_all[wave], tbl_w};
     sstate[lane] = SL_EMPTY;
 
     Lane L;
@@ -576,7 +579,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     vec3 nrm = mk(0, 0, 0);
                     if (__any(st == SL_HIT)) {
                         w_mlp_lane += 4u * (uint32_t)__popcll(__ballot(st == SL_HIT));
-                        nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, tbl_all[wave], lane, st == SL_HIT, hp, w_mlp_wave);
+                        nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, tbl_w, lane, st == SL_HIT, hp, w_mlp_wave);
                     }
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
