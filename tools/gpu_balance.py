@@ -31,7 +31,7 @@ for name in ("c2", "c4", "c5"):
     if name not in which:
         continue
     desc, sc, cfg, spp, env = config(name)
-    rec = {"workload": desc, "ranks": {}}
+    rec = {"workload": desc, "options": json.loads(os.environ.get("OPTS", "{}")), "ranks": {}}
     for G in (1, 2, 4, 8):
         tw, th = default_tile(cfg.width, cfg.height, G)
         times = []
@@ -41,6 +41,8 @@ for name in ("c2", "c4", "c5"):
                 r.set_env(env, 1.8, 2.2)
             if G > 1:
                 r.set_tiles(tw, th, rank, G)
+            for k, v in json.loads(os.environ.get("OPTS", "{}")).items():      # e.g. OPTS='{"jit": 1, "jit_bake": 1}' = bench.py's kernels
+                r.set_option(k, v)
             r.set_option("reserve_spp", spp)
             r.sample(1); r.sync()
             best = 1e9
