@@ -2,7 +2,7 @@
 the CPU oracle, compared bit for bit (image_buffer and the work counters).  ~6 minutes of oracle time on
 16 cores; the result is written to gpurun_out/fullsize_parity.json (copied to profiles/)."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle_backend import OracleRenderer, usable_cores

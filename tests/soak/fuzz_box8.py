@@ -1,6 +1,6 @@
 """One-off soak: many random 8-box scenes, HIP (default options) vs oracle, bit-exact."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from fuzz import random_box8_case, run

@@ -1,7 +1,7 @@
 """One-off soak: many random scenes of tests/fuzz.py::random_case, HIP vs oracle, bit-exact (image_buffer,
-image_pixels, ray_buffer, counters).  usage: gpu_fuzz_soak.py LO HI"""
+image_pixels, ray_buffer, counters).  usage: tests/soak/fuzz_soak.py LO HI"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from fuzz import random_case, run

@@ -3,7 +3,7 @@
 These are outputs of this repo's own oracle (the reference cannot run here: Taichi is not
 installed), committed so that (a) the oracle is guarded against drift across machines and
 compilers and (b) the GPU tests have a second, oracle-independent comparison target.
-  python tools/make_golden.py [case-name ...]
+  python tests/soak/make_golden.py [case-name ...]
 """
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from cases import all_cases, fingerprint          # noqa: E402

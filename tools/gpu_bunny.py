@@ -1,23 +1,17 @@
-"""C3 (glass bunny 1920x1080, 16 bounces) on the HIP path: parity spot check, throughput per option set, and the
-network's lane utilisation from the mlp_* counters.   python tools/gpu_bunny.py [spp] ['{"mlp_lanes": 32}' ...]"""
+"""C3 (glass bunny 1920x1080, 16 bounces) on the HIP path: throughput per option set and the network's slot utilisation
+from the mlp_* counters (parity: tests/test_gpu_parity.py, tests/test_gpu_fullsize.py).   python tools/gpu_bunny.py [spp] ['{"mlp_lanes": 32}' ...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import numpy as np
 from raytracingpbr_amd import SHAPE, Config, Renderer, bunny
 from raytracingpbr_amd.ibl import load_bunny_weights, synthetic_env
-from oracle_backend import OracleRenderer
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 variants = [json.loads(a) for a in sys.argv[2:]] or [{}]
 env = synthetic_env(3072, 1536, seed=0)
 def mk(R, sc, cfg):
     r = R(sc, cfg); r.set_env(env, 1.8, 2.2); r.set_shape_data(SHAPE.BUNNY, load_bunny_weights()); return r
 sc = bunny(aspect=16 / 9)
-small = Config.bunny_glass(240, 135, 0, 16)
-o = mk(OracleRenderer, sc, small); o.sample(4)
-g = mk(Renderer, sc, small); g.sample(4)
-print("bit-exact vs oracle (240x135x4):", np.array_equal(g.image_buffer.view(np.uint32), o.image_buffer.view(np.uint32)),
-      "mlp lane evals hip/oracle:", g.counter("mlp_lane_evals"), o.counter("mlp_lane_evals"), flush=True)
 cfg = Config.bunny_glass(1920, 1080, 0, 16)
 rs = []
 for opts in variants:
