@@ -101,6 +101,8 @@ def setup_variant(meta, env_u8=None):
         sc, cfg, ex = bunny(asp, chrome=True, v2=True), Config.bunny_sdf(W, H, 0, mr, frame, v2=True), 1.8
     elif v == "src":
         sc, cfg, ex = src_scene(asp), Config.src(W, H, 0), 1.4
+        if meta.get("adaptive_sampling"):
+            cfg = cfg.copy(adaptive_sampling=1, noise_threshold=meta["noise_threshold"])
     else:
         raise KeyError(v)
     o = OracleRenderer(sc, cfg, threads=0)
@@ -397,3 +399,35 @@ def test_src_launches():
         assert okp[now].all()
         same &= now
     assert same.mean() >= 0.95, (same.mean(), first)
+
+
+def test_src_adaptive_sampling_launches():
+    """ADAPTIVE_SAMPLING = True (src/config.py:14, NOISE_THRESHOLD raised to 0.05 so that pixels drop out within 40
+    launches): refresh presets the statistics (src/renderer.py:18-20), pathtrace() skips pixels whose running mean display
+    change fell to the threshold (src/pathtracer.py:97-101), post_process() updates diff_buffer / diff_pixels
+    (src/postprocessor.py:40-43).  Checked per launch: which pixels were sampled (sample count), the statistics, the state."""
+    d, meta = load("ref_src_adaptive.npz")
+    o = setup_variant(meta, d["env__u8"])
+    px = d["frame__pixels"]
+    o.refresh()
+    n = len(px)
+    same = np.ones(n, bool)
+    dropped_ref = 0
+    for k in range(meta["launches"]):
+        o.sample(1)
+        o.post_process()
+        ref_ib, ref_rb = d["frame__image_buffer"][k], d["frame__ray_buffer"][k]
+        ib = o.image_buffer[px[:, 0], px[:, 1]]
+        rb = o.ray_buffer[px[:, 0], px[:, 1]]
+        okn = ib[:, 3] == ref_ib[:, 3]                                                           # same launches sampled this pixel
+        okd = rb[:, 9].view(np.int32) == ref_rb[:, 9].astype(np.int32)
+        okb = np.all(np.isclose(ib, ref_ib, rtol=1e-2, atol=1e-6), axis=1)
+        oks = np.all(np.isclose(o.diff_buffer[px[:, 0], px[:, 1]], d["frame__diff_buffer"][k], rtol=2e-2, atol=2e-4), axis=1) & \
+            np.isclose(o.diff_pixels[px[:, 0], px[:, 1]], d["frame__diff_pixels"][k], rtol=2e-2, atol=2e-4)
+        now = okn & okd & okb & oks
+        new_split = same & ~now
+        assert new_split.sum() <= 2, (k, int(new_split.sum()))
+        same &= now
+        dropped_ref = int((d["frame__diff_pixels"][k] <= meta["noise_threshold"]).sum())
+    assert dropped_ref == n                     # the fixture does exercise the mask: every pixel has dropped out by the end
+    assert same.mean() >= 0.9, same.mean()

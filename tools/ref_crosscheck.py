@@ -255,7 +255,9 @@ def synthetic_env_u8(w, h):
     return v.astype(np.uint8)
 
 
-def run_src():
+def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_threshold=None):
+    """adaptive: the reference's ADAPTIVE_SAMPLING = True (src/config.py:14) — the constants are changed in its config
+    module before any of its other modules is imported, exactly what editing that line does"""
     ti, _rt = install_standin()
     sys.path.insert(0, REF)
     rng = Stream()
@@ -264,6 +266,10 @@ def run_src():
     env = synthetic_env_u8(EW, EH)
     _rt.imread = lambda path: env.copy()
     import src.config as config                          # noqa: E402  (the reference's package)
+    if adaptive:
+        config.ADAPTIVE_SAMPLING = True
+        if noise_threshold is not None:
+            config.NOISE_THRESHOLD = noise_threshold
     import src.scene as scene
     import src.sdf as sdf
     import src.pbr as pbr
@@ -317,8 +323,7 @@ def run_src():
     env_ref = ibl.hdr_map.img.to_numpy()                  # (EW,EH,3) after the reference's own preprocess
 
     # ---- in situ: pathtrace() on a pixel subset, K launches ----------------------------------------
-    pixels = grid_pixels(W, H, 24, 16)
-    K = 24
+    pixels = grid_pixels(W, H, *grid)
     _rt.pixels = lambda field: pixels if len(field.shape) == 2 else None
     state = dict(step=0, steps=0)
 
@@ -380,7 +385,7 @@ def run_src():
                           aspect=float(camera.aspect_ratio[None]), vfov=float(camera.camera_vfov[None]),
                           aperture=float(camera.camera_aperture[None]), focus=float(camera.camera_focus[None]))
     px = np.array(pixels)
-    hist_ray, hist_img, hist_pix = [], [], []
+    hist_ray, hist_img, hist_pix, hist_dbuf, hist_dpix = [], [], [], [], []
     t0 = time.time()
     for k in range(K):
         state["step"] = k
@@ -394,12 +399,18 @@ def run_src():
         hist_ray.append(np.concatenate([rb[:, :9], dep[:, None].astype(np.float32)], axis=1))
         hist_img.append(fileds.image_buffer.to_numpy()[px[:, 0], px[:, 1]])
         hist_pix.append(fileds.image_pixels.to_numpy()[px[:, 0], px[:, 1]])
+        if adaptive:
+            hist_dbuf.append(fileds.diff_buffer.to_numpy()[px[:, 0], px[:, 1]])
+            hist_dpix.append(fileds.diff_pixels.to_numpy()[px[:, 0], px[:, 1]])
         print(f"src launch {k}: {time.time() - t0:.0f} s", flush=True)
     arrays = rec.arrays()
+    if adaptive:                                          # the per-function observations are in ref_src.npz already
+        arrays = dict(frame__diff_buffer=np.array(hist_dbuf), frame__diff_pixels=np.array(hist_dpix))
+        meta["adaptive_sampling"], meta["noise_threshold"] = 1, float(config.NOISE_THRESHOLD)
     arrays.update(frame__pixels=px, frame__ray_buffer=np.array(hist_ray), frame__image_buffer=np.array(hist_img),
                   frame__image_pixels=np.array(hist_pix), env__u8=env, env__processed=env_ref)
     meta["launches"] = K
-    save("ref_src.npz", arrays, meta)
+    save(out, arrays, meta)
 
 
 # =================================================================== bunny (sd_bunny + one raycast set)
@@ -538,6 +549,7 @@ def _render(m):
 
 LEGS = dict(
     v3=run_v3, src=run_src, bunny=run_bunny,
+    src_adaptive=lambda: run_src(True, "ref_src_adaptive.npz", 40, (12, 8), 0.05),
     v3b8=lambda: run_v3(8, "ref_v3b8.npz", (20, 20), 3),
     v2=lambda: run_script("v2", "cornell_box", "cornell_box_v2", (0, 0, 35.0), _fused, (24, 24), 4),
     v1=lambda: run_script("v1", "cornell_box", "cornell_box", (0, 0, 3.0), _fused, (16, 16), 2),
