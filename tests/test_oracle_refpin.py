@@ -103,6 +103,8 @@ def setup_variant(meta, env_u8=None):
         sc, cfg, ex = src_scene(asp), Config.src(W, H, 0), 1.4
         if meta.get("adaptive_sampling"):
             cfg = cfg.copy(adaptive_sampling=1, noise_threshold=meta["noise_threshold"])
+        if meta.get("steps_per_launch", 1) != 1 or meta.get("black_background"):
+            cfg = cfg.copy(steps_per_launch=meta["steps_per_launch"], primary_miss=1 if meta["black_background"] else 0)
     else:
         raise KeyError(v)
     o = OracleRenderer(sc, cfg, threads=0)
@@ -431,3 +433,31 @@ def test_src_adaptive_sampling_launches():
         dropped_ref = int((d["frame__diff_pixels"][k] <= meta["noise_threshold"]).sum())
     assert dropped_ref == n                     # the fixture does exercise the mask: every pixel has dropped out by the end
     assert same.mean() >= 0.9, same.mean()
+
+
+def test_src_four_steps_per_launch_black_background():
+    """SAMPLES_PER_PIXEL = 4 (the unrolled loop of sample(), src/pathtracer.py:84-86) and BLACK_BACKGROUND = True
+    (src/pathtracer.py:33-34: a camera ray that escapes is black instead of sky-coloured), 12 launches of render()."""
+    d, meta = load("ref_src_spp4_black.npz")
+    assert meta["steps_per_launch"] == 4 and meta["black_background"] == 1
+    o = setup_variant(meta, d["env__u8"])
+    px = d["frame__pixels"]
+    o.refresh()
+    n = len(px)
+    same = np.ones(n, bool)
+    for k in range(meta["launches"]):
+        o.sample(1)
+        o.post_process()
+        rb = o.ray_buffer[px[:, 0], px[:, 1]]
+        ref = d["frame__ray_buffer"][k]
+        okd = rb[:, 9].view(np.int32) == ref[:, 9].astype(np.int32)
+        okc = np.all(np.isclose(rb[:, 6:9], ref[:, 6:9], rtol=1e-2, atol=1e-6), axis=1)
+        okb = np.all(np.isclose(o.image_buffer[px[:, 0], px[:, 1]], d["frame__image_buffer"][k], rtol=1e-2, atol=1e-6), axis=1)
+        now = okd & okc & okb
+        new_split = same & ~now
+        assert new_split.sum() <= max(2, 0.01 * n), (k, int(new_split.sum()))
+        same &= now
+    assert same.mean() >= 0.93, same.mean()
+    # the black background did act: some pixels finished samples with exactly zero radiance
+    ib = d["frame__image_buffer"][-1]
+    assert ((ib[:, 3] > 0) & (ib[:, :3].sum(axis=1) == 0)).any()

@@ -255,7 +255,7 @@ def synthetic_env_u8(w, h):
     return v.astype(np.uint8)
 
 
-def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_threshold=None):
+def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_threshold=None, spp=1, black=False):
     """adaptive: the reference's ADAPTIVE_SAMPLING = True (src/config.py:14) — the constants are changed in its config
     module before any of its other modules is imported, exactly what editing that line does"""
     ti, _rt = install_standin()
@@ -270,6 +270,8 @@ def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_thresh
         config.ADAPTIVE_SAMPLING = True
         if noise_threshold is not None:
             config.NOISE_THRESHOLD = noise_threshold
+    config.SAMPLES_PER_PIXEL = spp                        # bounce-steps per launch (src/config.py:10)
+    config.BLACK_BACKGROUND = black                       # src/config.py:13
     import src.scene as scene
     import src.sdf as sdf
     import src.pbr as pbr
@@ -329,8 +331,16 @@ def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_thresh
 
     def on_index(ix):
         if len(ix) == 2:
-            rng.seek(ix[0], ix[1], state["step"])
+            state["sub"] = 0
+            rng.seek(ix[0], ix[1], state["step"] * spp)
     _rt.on_index = on_index
+    o_rr = pathtracer.russian_roulette
+
+    def russian_roulette(ray, i, j):                      # one bounce-step = one stream, keyed by the absolute step index
+        rng.seek(i, j, state["step"] * spp + state["sub"])
+        state["sub"] += 1
+        return o_rr(ray, i, j)
+    pathtracer.russian_roulette = russian_roulette
 
     o_raycast, o_rsi, o_gen, o_sky = pathtracer.raycast, pathtracer.ray_surface_interaction, pathtracer.gen_ray, pathtracer.sky_color
     o_nearest = scene.nearest
@@ -407,6 +417,9 @@ def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_thresh
     if adaptive:                                          # the per-function observations are in ref_src.npz already
         arrays = dict(frame__diff_buffer=np.array(hist_dbuf), frame__diff_pixels=np.array(hist_dpix))
         meta["adaptive_sampling"], meta["noise_threshold"] = 1, float(config.NOISE_THRESHOLD)
+    elif spp != 1 or black:
+        arrays = {}
+    meta["steps_per_launch"], meta["black_background"] = spp, int(black)
     arrays.update(frame__pixels=px, frame__ray_buffer=np.array(hist_ray), frame__image_buffer=np.array(hist_img),
                   frame__image_pixels=np.array(hist_pix), env__u8=env, env__processed=env_ref)
     meta["launches"] = K
@@ -550,6 +563,7 @@ def _render(m):
 LEGS = dict(
     v3=run_v3, src=run_src, bunny=run_bunny,
     src_adaptive=lambda: run_src(True, "ref_src_adaptive.npz", 40, (12, 8), 0.05),
+    src_spp4_black=lambda: run_src(False, "ref_src_spp4_black.npz", 12, (16, 10), spp=4, black=True),
     v3b8=lambda: run_v3(8, "ref_v3b8.npz", (20, 20), 3),
     v2=lambda: run_script("v2", "cornell_box", "cornell_box_v2", (0, 0, 35.0), _fused, (24, 24), 4),
     v1=lambda: run_script("v1", "cornell_box", "cornell_box", (0, 0, 3.0), _fused, (16, 16), 2),
