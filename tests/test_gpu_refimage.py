@@ -118,3 +118,16 @@ def test_png_wall_colours_are_outside_the_committed_tone_map():
     back = ref[160:192, 224:256].reshape(-1, 3).mean(0)
     sol = least_squares(lambda c: tm(c) - back, x0=np.array([0.5, 0.5, 0.5]))
     assert sol.x.min() > 0.5 and sol.x.max() / sol.x.min() < 1.15
+
+
+@pytest.mark.gpu
+def test_bunny_outline_matches_the_published_image_on_hip():
+    """The neural-SDF bunny's outline in others/sdf_bunny_glass.jpg against the HIP path's primary-ray hit mask (see
+    tests/test_oracle_refimage_bunny.py for the method and the finding about the animation's bob)."""
+    from test_oracle_refimage_bunny import hit_mask, iou, silhouette
+    from raytracingpbr_amd import Renderer
+    ref = silhouette()
+    m = hit_mask(60, True, make=Renderer)
+    assert iou(m, ref) >= 0.96
+    assert np.array_equal(m, hit_mask(60, True))           # the same mask as the CPU oracle's
+    assert iou(hit_mask(60, False, make=Renderer), ref) < 0.8
