@@ -154,6 +154,8 @@ def main():
     # nccl gathers device tensors (RCCL over xGMI); the gloo functional mode stages through the host
     tg = TileGather(r, rank, world, device=dev if a.backend == "nccl" else None) if world > 1 else None
     r.set_option("reserve_spp", SPP)     # device buffers are allocated before the timed region, whatever --warmup is
+    r.sample(1)                          # ... and the run-time kernels are compiled / loaded (~1 s the first time) even with --warmup 0
+    r.sync()
 
     def step():
         r.refresh()
