@@ -144,7 +144,9 @@ def test_schedule_independence():
                  {"scheduler": 0, "wait_lanes": 7, "waves_per_cu": 4}, {"scheduler": 0},
                  {"scheduler": 1, "shade_lanes": 1, "swap_lanes": 1}, {"scheduler": 1, "shade_lanes": 64, "swap_lanes": 64},
                  {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
-                 {"refill_lanes": 1, "ready_low": 0}, {"refill_lanes": 64, "ready_low": 63}, {"ready_low": 17}, {"refill_lanes": 40, "shade_lanes": 20, "primary_split": 2},
+                 {"refill_lanes": 1, "ready_low": 0}, {"refill_lanes": 64, "ready_low": 63}, {"ready_low": 17},
+                 {"chunk": 64}, {"chunk": 1 << 20}, {"chunk": 777, "primary_split": 2},
+                 {"jit": 2, "jit_waves": 7}, {"jit": 2, "jit_bake": 1, "jit_waves": 4, "chunk": 96}, {"refill_lanes": 40, "shade_lanes": 20, "primary_split": 2},
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
                  {"primary_split": 0}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
                  {"primary_split": 2, "specialize": 0}, {"primary_split": 2, "staging_bytes": 1 << 20, "shade_lanes": 3},
