@@ -304,7 +304,12 @@ def test_staging_allocation_failure_falls_back_to_fewer_samples_per_launch():
     ref.close()
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(free - (1500 << 20), dtype=torch.uint8, device="cuda")     # leave 1.5 GB
+    if free < (16 << 30):
+        pytest.skip("the device is shared: cannot stage an out-of-memory condition safely")
+    try:
+        hog = torch.empty(free - (2000 << 20), dtype=torch.uint8, device="cuda")     # leave 2 GB
+    except RuntimeError as e:                                                        # pragma: no cover
+        pytest.skip("could not fill the device: %s" % e)
     try:
         r = Renderer(sc, cfg)
         r.sample(SPP)
