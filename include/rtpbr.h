@@ -339,7 +339,7 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * table and the whole rtpbr_config except seed and frame as compile-time constants — one code object per scene and
  * configuration; for offline renders of a fixed scene),
  * "jit_waves" (waves per SIMD the run-time pool kernel is compiled for; 0 = as the ahead-of-time instances),
- * "chunk" (work items a wave claims per atomic; 0 = automatic: total / (waves x 64) clamped to [256, 1024]),
+ * "chunk" (work items a wave claims per atomic, at most 8192; 0 = automatic: total / (waves x 64) clamped to [256, 1024]),
  * "reserve_spp" (allocate the staging of a call of that many samples per pixel now instead of on
  * first use), "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */

@@ -83,6 +83,8 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->stage);
     (void)hipFree(c->primary);
     rt_rccl_release(c);
+    rt_jit_release(c->jit_mod);
+    c->jit_mod = nullptr;
     (void)hipFree(c->work_counter);
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -485,6 +487,10 @@ static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
     return (int)grid;
 }
 
+// Room kept free below 2^32 for the claims the last waves make past the end of the work (one failing claim per wave):
+// at most 32 waves per CU, at most 8192 items per claim (option "chunk" is clamped to that).
+static long long work_margin(const rtpbr_ctx* c) { return (long long)(c->n_cu > 0 ? c->n_cu : 256) * 32LL * 8192LL; }
+
 extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
@@ -542,6 +548,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.box_4rho2m *= 4.0f;
     }
     // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
+    rt_jit_release(c->jit_mod);
     c->jit_mod = nullptr;
     const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1 && c->mlp_mfma;   // configuration baking only
     const bool persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
@@ -646,7 +653,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             if (kmax < 1) kmax = 1;
             // keep total_items within 32 bits
             // (minus the chunks the last waves claim past the end: the work counter must not wrap)
-            long long k32 = (0xFFFFFFFFLL - (64LL << 20)) / (long long)P.np;
+            long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)P.np;
             if (k32 < 1) k32 = 1;
             if (kmax > k32) kmax = k32;
             int K = (int)(left < kmax ? left : kmax);
@@ -896,7 +903,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 8) return fail(RTPBR_EINVAL, "jit_waves must be 0 (default) .. 8");
         c->jit_waves = (int)value;
     } else if (!strcmp(key, "chunk")) {
-        if (value < 0 || value > (1 << 20)) return fail(RTPBR_EINVAL, "chunk must be 0 (automatic) .. 2^20");
+        // every wave makes one claim past the end, so the 32-bit work counter overshoots by waves x chunk: the margin kept
+        // free below 2^32 (work_margin) covers 32 waves per CU x 8192
+        if (value < 0 || value > 8192) return fail(RTPBR_EINVAL, "chunk must be 0 (automatic) .. 8192");
         c->chunk = (int)value;
     } else if (!strcmp(key, "ready_low")) {
         if (value < 0 || value > 63) return fail(RTPBR_EINVAL, "ready_low must be 0..63");
@@ -947,7 +956,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
         long long per_spp = (long long)c->P.np * (long long)(sizeof(float4) + (split_ok ? sizeof(float2) : 0));
         long long kmax = c->staging_bytes / per_spp;
-        long long k32 = (0xFFFFFFFFLL - (64LL << 20)) / (long long)c->P.np;
+        long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)c->P.np;
         if (k32 < 1) k32 = 1;
         if (kmax > k32) kmax = k32;
         if (kmax < 1) kmax = 1;

@@ -43,10 +43,14 @@ struct RtJitModule {
     hipFunction_t trace = nullptr, primary = nullptr, persistent_pool = nullptr, persistent_steps = nullptr;
     int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0;
     std::string path;
+    int device = 0;
+    int pins = 0;                       // contexts whose last rtpbr_sample() used this instance (never unloaded while > 0)
+    unsigned long long last_use = 0;    // LRU clock of the registry
 };
 struct rtpbr_ctx;
-int rt_jit_build(const RtJitKey& key, std::string* out);
-int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out);
+int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic);
+int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out);   // returns the instance pinned
+void rt_jit_release(RtJitModule* m);
 int rt_jit_launch(hipFunction_t f, const rt::Params& P, unsigned grid, hipStream_t st);
 int rt_jit_launch_steps(hipFunction_t f, const rt::Params& P, int steps, unsigned grid, hipStream_t st);
 
@@ -122,17 +126,19 @@ struct rtpbr_ctx {
     bool timed = false;
     int n_cu = 256;
     // run-time compiled instance of the current scene (rt_jit.hip): -1 = when no ahead-of-time specialisation serves
-    // the scene, 0 = never, 1 = always (an error if it cannot be built)
+    // the scene, 0 = never, 1 = always (falling back to the ahead-of-time kernels if it cannot be built), 2 = always, an
+    // error otherwise
     int jit = -1;
     int jit_bake = 0;                 // 1: run-time instances carry the scene's constants as literals
-    RtJitModule* jit_mod = nullptr;   // the one the last rtpbr_sample() used (nullptr = ahead-of-time instance)
+    RtJitModule* jit_mod = nullptr;   // the one the last rtpbr_sample() used, pinned until the next one (nullptr = ahead-of-time instance)
     unsigned jit_sig = 0;
     // multi-GPU gather (rt_rccl.hip): communicator handle (ncclComm_t) and the packed-tile buffers
     void* comm = nullptr;
     int comm_rank = 0, comm_world = 1;
     void* gather_send = nullptr;
     void* gather_recv = nullptr;
-    size_t gather_cap = 0;
+    size_t gather_cap = 0;        // bytes of gather_send
+    size_t gather_recv_cap = 0;   // bytes of gather_recv (rank 0: local share x world)
 };
 void rt_rccl_release(rtpbr_ctx* c);
 

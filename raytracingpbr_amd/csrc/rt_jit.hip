@@ -7,14 +7,34 @@
 // rotation classes and the culling decision as compile-time constants; ~2 s), cached as a code object under
 // $RTPBR_JIT_CACHE / $XDG_CACHE_HOME/rtpbr / ~/.cache/rtpbr keyed by those constants and a hash of the sources, loaded
 // with hipModuleLoadData and launched with hipModuleLaunchKernel.  Results are bit-identical to the ahead-of-time
-// instances (same arithmetic).  If hipcc or the sources are not available the library silently keeps using the
-// ahead-of-time instance (option "jit" = 1 turns that into an error, 0 disables run-time compilation).
+// instances (same arithmetic).  If hipcc or the sources are not available the library keeps using the ahead-of-time
+// instance (option "jit": -1 = when no ahead-of-time specialisation serves the scene, 0 = never, 1 = always with that
+// fallback, 2 = always and an error otherwise).
+//
+// Trust: a code object is executed inside the caller's GPU context, so the cache must not be writable by anybody
+// else.  The cache directory is created with mode 0700 and is only used when lstat() shows a real directory owned by
+// this user with no group/other write bit; a code object is read through one O_NOFOLLOW descriptor that fstat() shows
+// to be a regular file of this user (no check-then-open race).  When $HOME is unusable the fallback is the PER-USER
+// /tmp/rtpbr-cache-<uid>, held to the same checks; if no candidate passes, run-time compilation is off and the
+// ahead-of-time kernels serve the scene.
+//
+// Concurrency: compilation (~2 s) runs OUTSIDE the process-wide lock behind a per-key "building" marker — other keys,
+// contexts and threads proceed; threads that want the same key wait for it.  Only deterministic failures (hipcc ran
+// and rejected the unit, sources missing) are remembered; transient ones (fork, disk, a stale object that was
+// removed) are retried by the next call.  Loaded modules are reference-counted by the contexts that use them and
+// the least recently used unpinned ones are unloaded beyond RTPBR_JIT_MAX_MODULES (default 64); baked code objects on
+// disk are pruned, oldest first, beyond RTPBR_JIT_CACHE_MAX files (default 512).
+#include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cerrno>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,9 +47,20 @@
 
 using namespace rt;
 
+extern "C" const char* rtpbr_last_error(void);
+
 namespace {
+// process-wide registry: contexts on the same device share code objects
+enum { E_BUILDING = 0, E_READY = 1, E_FAILED = 2 };
+struct Entry {
+    int state = E_BUILDING;
+    RtJitModule* mod = nullptr;
+    std::string error;        // E_FAILED: the (deterministic) reason
+};
 std::mutex g_mu;
-std::map<std::string, RtJitModule*> g_modules;   // process-wide: contexts on the same device share code objects
+std::condition_variable g_cv;
+std::map<std::string, Entry> g_modules;
+unsigned long long g_tick = 0;   // LRU clock
 
 std::string lib_dir() {
     Dl_info info;
@@ -64,16 +95,75 @@ bool source_hash(const std::string& dir, uint64_t* h) {
     return true;
 }
 
-std::string cache_dir() {
-    if (const char* e = getenv("RTPBR_JIT_CACHE")) return e;
-    if (const char* e = getenv("XDG_CACHE_HOME")) return std::string(e) + "/rtpbr";
-    if (const char* e = getenv("HOME")) return std::string(e) + "/.cache/rtpbr";
-    return "/tmp/rtpbr-cache";
+// A code object from the cache: ONE descriptor, opened without following a symlink, that fstat() shows to be a regular
+// file owned by this user and not writable by group or others — what is checked is what is read.
+bool read_owned_file(const std::string& path, std::vector<char>& out) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && st.st_size > 0;
+    if (ok) {
+        out.resize((size_t)st.st_size);
+        size_t got = 0;
+        while (got < out.size()) {
+            const ssize_t k = read(fd, out.data() + got, out.size() - got);
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        ok = got == out.size();
+    }
+    close(fd);
+    return ok;
 }
 
-void mkdirs(const std::string& d) {
+// mkdir -p; the LEAF is created 0700.  Then the leaf must be a real directory (not a symlink) of this user that nobody
+// else can write to — a directory somebody else prepared (or can write into) is never used.
+bool secure_dir(const std::string& d) {
     for (size_t i = 1; i <= d.size(); i++)
-        if (i == d.size() || d[i] == '/') mkdir(d.substr(0, i).c_str(), 0755);
+        if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), i == d.size() ? 0700 : 0755);
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+// The first candidate that passes secure_dir(): $RTPBR_JIT_CACHE (the only candidate when set), $XDG_CACHE_HOME/rtpbr,
+// ~/.cache/rtpbr, then the per-user /tmp/rtpbr-cache-<uid> (read-only or missing home).  Empty = run-time compilation off.
+std::string cache_dir() {
+    std::vector<std::string> cand;
+    if (const char* e = getenv("RTPBR_JIT_CACHE")) {
+        cand.push_back(e);
+    } else {
+        if (const char* x = getenv("XDG_CACHE_HOME")) cand.push_back(std::string(x) + "/rtpbr");
+        else if (const char* h = getenv("HOME")) cand.push_back(std::string(h) + "/.cache/rtpbr");
+        char alt[64];
+        snprintf(alt, sizeof alt, "/tmp/rtpbr-cache-%d", (int)getuid());
+        cand.push_back(alt);
+    }
+    for (const std::string& d : cand)
+        if (!d.empty() && secure_dir(d)) return d;
+    return "";
+}
+
+// keep at most RTPBR_JIT_CACHE_MAX (default 512) code objects in the cache: a baked instance exists per (scene, config),
+// an animation bakes one per frame.  Oldest (mtime) first; files of other processes' builds in flight (.tmp.) are left alone.
+void prune_cache(const std::string& dir) {
+    long cap = 512;
+    if (const char* e = getenv("RTPBR_JIT_CACHE_MAX")) cap = atol(e);
+    if (cap < 1) cap = 1;
+    DIR* d = opendir(dir.c_str());
+    if (!d) return;
+    std::vector<std::pair<long long, std::string>> files;
+    while (dirent* e = readdir(d)) {
+        const std::string n = e->d_name;
+        if (n.size() < 7 || n.compare(n.size() - 6, 6, ".hsaco") != 0) continue;
+        struct stat st;
+        if (lstat((dir + "/" + n).c_str(), &st) == 0 && S_ISREG(st.st_mode))
+            files.push_back({(long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec, n});
+    }
+    closedir(d);
+    if ((long)files.size() <= cap) return;
+    std::sort(files.begin(), files.end());
+    for (size_t i = 0; i + (size_t)cap < files.size(); i++) unlink((dir + "/" + files[i].second).c_str());
 }
 
 std::string hipcc_path() {
@@ -99,53 +189,60 @@ int run(const std::vector<std::string>& argv, const std::string& log) {
         _exit(127);
     }
     int st = 0;
-    if (waitpid(pid, &st, 0) < 0) return -1;
+    for (;;) {
+        if (waitpid(pid, &st, 0) >= 0) break;
+        if (errno == EINTR) continue;
+        // ECHILD: the host ignores SIGCHLD (or reaps children itself), the exit status is gone — the caller decides by
+        // whether the output file exists
+        return errno == ECHILD ? -2 : -1;
+    }
     return WIFEXITED(st) ? WEXITSTATUS(st) : -1;
 }
 }  // namespace
 
+static uint64_t baked_hash(const RtJitKey& key) {
+    if (!key.baked) return 0;
+    uint64_t th = 1469598103934665603ull;
+    for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
+    for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
+    for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
+    for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
+    return th;
+}
+
 // Compile (or fetch from the cache) the code object of `key`; path of the .hsaco in *out.  Needs no device.
-int rt_jit_build(const RtJitKey& key, std::string* out) {
+// *deterministic (optional) is set when a failure would repeat on every call (hipcc rejected the unit, sources missing).
+int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
+    if (deterministic) *deterministic = false;
     const std::string dir = lib_dir();
     uint64_t sh = 0;
-    if (!source_hash(dir, &sh)) return rt_fail(RTPBR_ESTATE, "run-time compilation: kernel sources not found next to the library (%s)", dir.c_str());
-    uint64_t th = 0;
-    if (key.baked) {
-        th = 1469598103934665603ull;
-        for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
-        for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
-        for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
-        for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
+    if (!source_hash(dir, &sh)) {
+        if (deterministic) *deterministic = true;
+        return rt_fail(RTPBR_ESTATE, "run-time compilation: kernel sources not found next to the library (%s)", dir.c_str());
     }
+    const uint64_t th = baked_hash(key);
     char name[256];
     snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
              key.cull, key.waves, (unsigned long long)th, (unsigned long long)sh);
-    std::string cdir = cache_dir();
-    std::string path = cdir + "/" + name + ".hsaco";
-    if (access(path.c_str(), R_OK) == 0) {
-        *out = path;
-        return RTPBR_OK;
-    }
-    mkdirs(cdir);
-    if (access(cdir.c_str(), W_OK) != 0 && !getenv("RTPBR_JIT_CACHE")) {
-        // read-only home directory: fall back to a per-user directory under /tmp rather than lose the specialisation
-        char alt[64];
-        snprintf(alt, sizeof alt, "/tmp/rtpbr-cache-%d", (int)getuid());
-        cdir = alt;
-        path = cdir + "/" + name + ".hsaco";
-        if (access(path.c_str(), R_OK) == 0) {
+    const std::string cdir = cache_dir();
+    if (cdir.empty())
+        return rt_fail(RTPBR_ESTATE, "run-time compilation is off: no cache directory that is owned by this user and closed to others "
+                                     "(tried $RTPBR_JIT_CACHE, else $XDG_CACHE_HOME/rtpbr or ~/.cache/rtpbr, then /tmp/rtpbr-cache-<uid>)%s", "");
+    const std::string path = cdir + "/" + name + ".hsaco";
+    {
+        std::vector<char> probe;
+        if (read_owned_file(path, probe)) {      // a cache hit must pass the same ownership test the loader applies
             *out = path;
             return RTPBR_OK;
         }
-        mkdirs(cdir);
     }
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
     // everything this process writes carries its pid: ranks of one job build the same key at the same time
     const std::string tpath = path + tmp, log = tpath + ".log";
     std::string table_def;
+    const std::string tfile = tpath + ".table.hpp";
     if (key.baked) {
-        const std::string tfile = tpath + ".table.hpp";
         FILE* f = fopen(tfile.c_str(), "w");
         if (!f) return rt_fail(RTPBR_ESTATE, "cannot write %s", tfile.c_str());
         fprintf(f, "// generated by rt_jit.hip: the scene's march table (ObjM blocks) as bit patterns\n");
@@ -186,46 +283,110 @@ int rt_jit_build(const RtJitKey& key, std::string* out) {
                                      d[0], d[1], d[2], d[3], d[4], d[5], dir + "/rt_jit_tu.hip", "-o", tpath};
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     const int rc = run(argv, log);
-    if (rc != 0 || access(tpath.c_str(), R_OK) != 0) {
+    struct stat ost;
+    const bool have_out = stat(tpath.c_str(), &ost) == 0 && ost.st_size > 0;
+    // rc -2: the exit status was lost (SIGCHLD ignored by the host): a complete output file decides
+    if (!((rc == 0 || rc == -2) && have_out)) {
         unlink(tpath.c_str());
+        if (key.baked) unlink(tfile.c_str());
+        // hipcc ran and said no (or could not be run at all): the same call fails the same way next time
+        if (deterministic) *deterministic = rc > 0;
         return rt_fail(RTPBR_ESTATE, "run-time compilation failed (hipcc log: %s)", log.c_str());
     }
+    (void)chmod(tpath.c_str(), 0600);
     if (rename(tpath.c_str(), path.c_str()) != 0) {
         unlink(tpath.c_str());
         return rt_fail(RTPBR_ESTATE, "cannot move the compiled code object into the cache (%s)", path.c_str());
     }
     unlink(log.c_str());
-    if (key.baked) unlink((tpath + ".table.hpp").c_str());
+    if (key.baked) unlink(tfile.c_str());
+    prune_cache(cdir);
     *out = path;
     return RTPBR_OK;
 }
 
-int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
-    uint64_t th = 0;
-    if (key.baked) {
-        th = 1469598103934665603ull;
-        for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
-        for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
-        for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
-        for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
+static void unload_module(RtJitModule* m) {
+    // kernels of a context that has moved on to another instance may still be in flight
+    if (hipSetDevice(m->device) == hipSuccess) (void)hipDeviceSynchronize();
+    if (m->module) (void)hipModuleUnload(m->module);
+    delete m;
+}
+
+// keep at most RTPBR_JIT_MAX_MODULES loaded instances (g_mu held): unload the least recently used unpinned ones
+static void evict_modules() {
+    long cap = 64;
+    if (const char* e = getenv("RTPBR_JIT_MAX_MODULES")) cap = atol(e);
+    if (cap < 1) cap = 1;
+    for (;;) {
+        long n = 0;
+        auto victim = g_modules.end();
+        for (auto it = g_modules.begin(); it != g_modules.end(); ++it) {
+            if (it->second.state != E_READY) continue;
+            n++;
+            if (it->second.mod->pins == 0 && (victim == g_modules.end() || it->second.mod->last_use < victim->second.mod->last_use)) victim = it;
+        }
+        if (n <= cap || victim == g_modules.end()) return;
+        unload_module(victim->second.mod);
+        g_modules.erase(victim);
     }
+}
+
+// The instance of `key` on c's device, PINNED (rt_jit_release when the context stops using it).
+int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     char id[224];
     snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, (unsigned long long)th);
-    std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_modules.find(id);
-    if (it != g_modules.end()) {
-        *out = it->second;
-        return it->second ? RTPBR_OK : rt_fail(RTPBR_ESTATE, "run-time compilation failed earlier for this scene");
+             key.cull, key.waves, (unsigned long long)baked_hash(key));
+    {
+        std::unique_lock<std::mutex> lock(g_mu);
+        for (;;) {
+            auto it = g_modules.find(id);
+            if (it == g_modules.end()) break;                       // ours to build
+            if (it->second.state == E_READY) {
+                it->second.mod->pins++;
+                it->second.mod->last_use = ++g_tick;
+                *out = it->second.mod;
+                return RTPBR_OK;
+            }
+            if (it->second.state == E_FAILED)
+                return rt_fail(RTPBR_ESTATE, "run-time compilation failed earlier for this scene: %s", it->second.error.c_str());
+            g_cv.wait(lock);                                         // another thread is building this key
+        }
+        g_modules[id] = Entry{};                                     // E_BUILDING
     }
-    g_modules[id] = nullptr;                         // a failure is remembered: no recompilation storm
+    // ---- compile and load WITHOUT the registry lock: other keys, contexts and threads proceed
+    auto settle = [&](RtJitModule* m, bool remember_failure, const char* why) {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (m) {
+            Entry& e = g_modules[id];
+            e.state = E_READY;
+            e.mod = m;
+            m->pins = 1;
+            m->last_use = ++g_tick;
+            evict_modules();
+        } else if (remember_failure) {
+            Entry& e = g_modules[id];
+            e.state = E_FAILED;
+            e.error = why ? why : "";
+        } else {
+            g_modules.erase(id);                                     // transient: the next call tries again
+        }
+        g_cv.notify_all();
+    };
     std::string path;
-    if (int r = rt_jit_build(key, &path)) return r;
+    bool deterministic = false;
+    if (int r = rt_jit_build(key, &path, &deterministic)) {
+        settle(nullptr, deterministic, rtpbr_last_error());
+        return r;
+    }
     std::vector<char> image;
-    if (!read_file(path, image) || image.empty()) return rt_fail(RTPBR_ESTATE, "cannot read %s", path.c_str());
-    RT_HIP_TRY(hipSetDevice(c->device));
+    if (!read_owned_file(path, image)) {
+        settle(nullptr, false, nullptr);
+        return rt_fail(RTPBR_ESTATE, "cannot read %s (or it is not a private file of this user)", path.c_str());
+    }
+    hipError_t e = hipSetDevice(c->device);
     RtJitModule* m = new RtJitModule();
-    hipError_t e = hipModuleLoadData(&m->module, image.data());
+    m->device = c->device;
+    if (e == hipSuccess) e = hipModuleLoadData(&m->module, image.data());
     if (e == hipSuccess) e = hipModuleGetFunction(&m->trace, m->module, "rt_jit_trace");
     if (e == hipSuccess) e = hipModuleGetFunction(&m->primary, m->module, "rt_jit_primary");
     if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_pool, m->module, "rt_jit_persistent_pool");
@@ -233,14 +394,22 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->trace_blocks_per_cu, m->trace, 256, 0);
     if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->persistent_blocks_per_cu, m->persistent_pool, 256, 0);
     if (e != hipSuccess) {
+        if (m->module) (void)hipModuleUnload(m->module);
         delete m;
-        unlink(path.c_str());                        // a stale / foreign code object: recompile next time
+        unlink(path.c_str());                        // a stale / truncated code object: the next call recompiles
+        settle(nullptr, false, nullptr);
         return rt_fail_hip("loading the run-time compiled code object", e);
     }
     m->path = path;
-    g_modules[id] = m;
+    settle(m, false, nullptr);
     *out = m;
     return RTPBR_OK;
+}
+
+void rt_jit_release(RtJitModule* m) {
+    if (!m) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (m->pins > 0) m->pins--;
 }
 
 int rt_jit_launch(hipFunction_t f, const Params& P, unsigned grid, hipStream_t st) {
@@ -262,7 +431,7 @@ extern "C" int rtpbr_test_jit_build(int kind, int n_obj, unsigned long long type
     RtJitKey k{};
     k.kind = kind, k.n_obj = n_obj, k.types = types, k.sig = sig, k.cull = cull, k.waves = waves;
     std::string p;
-    if (int r = rt_jit_build(k, &p)) return r;
+    if (int r = rt_jit_build(k, &p, nullptr)) return r;
     if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());
     return RTPBR_OK;
 }

@@ -83,18 +83,26 @@ extern "C" int rtpbr_rccl_unique_id(void* out, size_t nbytes) {
     return RTPBR_OK;
 }
 
-// Buffers of one rank: its packed tiles, and on rank 0 room for every rank's.
+// Buffers of one rank: its packed tiles, and on rank 0 room for every rank's.  The two capacities are tracked separately:
+// the receive side scales with the world size, which can change (rtpbr_set_tiles) while the local share stays the same.
 static int ensure_gather_buffers(rtpbr_ctx* c) {
     const size_t bytes = (size_t)c->P.np * sizeof(float4);
-    if (bytes > c->gather_cap || (c->rank == 0) != (c->gather_recv != nullptr)) {
+    const size_t recv_bytes = c->rank == 0 ? bytes * (size_t)c->world : 0;
+    if (bytes > c->gather_cap) {
         RT_HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->gather_send);
-        (void)hipFree(c->gather_recv);
-        c->gather_send = c->gather_recv = nullptr;
+        c->gather_send = nullptr;
         c->gather_cap = 0;
         RT_HIP_TRY(hipMalloc(&c->gather_send, bytes));
-        if (c->rank == 0) RT_HIP_TRY(hipMalloc(&c->gather_recv, bytes * (size_t)c->world));
         c->gather_cap = bytes;
+    }
+    if (recv_bytes > c->gather_recv_cap) {
+        RT_HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->gather_recv);
+        c->gather_recv = nullptr;
+        c->gather_recv_cap = 0;
+        RT_HIP_TRY(hipMalloc(&c->gather_recv, recv_bytes));
+        c->gather_recv_cap = recv_bytes;
     }
     return RTPBR_OK;
 }
@@ -204,4 +212,5 @@ void rt_rccl_release(rtpbr_ctx* c) {
     (void)hipFree(c->gather_send);
     (void)hipFree(c->gather_recv);
     c->gather_send = c->gather_recv = nullptr;
+    c->gather_cap = c->gather_recv_cap = 0;
 }

@@ -260,4 +260,74 @@ def test_run_time_compilation_survives_an_unwritable_home(monkeypatch):
     path = buf.value.decode()
     want = "/tmp/rtpbr-cache-%d/" % os.getuid()
     assert path.startswith(want) and os.path.getsize(path) > 10000
+    st = os.stat(want)
+    assert st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0            # created private (0700)
+    assert (os.stat(path).st_mode & 0o022) == 0
     shutil.rmtree(want, ignore_errors=True)
+
+
+def _jit_build(lib):
+    f = lib.rtpbr_test_jit_build
+    f.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    lib.rtpbr_last_error.restype = C.c_char_p
+    return f
+
+
+def test_run_time_cache_refuses_directories_and_files_others_can_write(tmp_path, monkeypatch):
+    """A code object runs inside the caller's GPU context, so the cache is only used when nobody else can have put it there
+    (ADVICE round 2): a group/world-writable cache directory, a symlinked one, and a cached file that others can write
+    are all refused — no compilation into them, no load from them."""
+    from raytracingpbr_amd import _capi
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    f = _jit_build(lib)
+    buf = C.create_string_buffer(512)
+    # (1) directory writable by others
+    bad = tmp_path / "shared"
+    bad.mkdir()
+    os.chmod(bad, 0o777)
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(bad))
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) != 0 and b"run-time compilation is off" in lib.rtpbr_last_error()
+    assert os.listdir(bad) == []
+    # (2) a symlink where the directory should be (somebody else's target)
+    real = tmp_path / "real"
+    real.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    os.symlink(real, link)
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(link))
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) != 0 and os.listdir(real) == []
+    # (3) a private directory works, and is created 0700 when missing
+    good = tmp_path / "good" / "rtpbr"
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(good))
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0, lib.rtpbr_last_error()
+    path = buf.value.decode()
+    assert path.startswith(str(good)) and (os.stat(good).st_mode & 0o077) == 0
+    # (4) the cached file made writable by others is no longer trusted: it is rebuilt (new inode, private mode), not loaded
+    os.chmod(path, 0o666)
+    ino = os.stat(path).st_ino
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0 and buf.value.decode() == path
+    st = os.stat(path)
+    assert (st.st_mode & 0o022) == 0 and st.st_ino != ino
+    # (5) a symlink in place of the cached file is not followed
+    os.unlink(path)
+    other = tmp_path / "evil.hsaco"
+    other.write_bytes(b"\x7fELF" + b"\0" * 20000)
+    os.symlink(other, path)
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0
+    assert not os.path.islink(path) and other.read_bytes()[:4] == b"\x7fELF" and os.path.getsize(other) == 20004
+
+
+def test_run_time_cache_is_bounded(tmp_path, monkeypatch):
+    """RTPBR_JIT_CACHE_MAX: oldest code objects go when the cache holds more than that many."""
+    from raytracingpbr_amd import _capi
+    lib = C.CDLL(_capi.HIP_LIB_PATH)
+    f = _jit_build(lib)
+    buf = C.create_string_buffer(512)
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("RTPBR_JIT_CACHE_MAX", "2")
+    for i in range(3):                                      # stale entries, oldest first
+        q = tmp_path / ("old%d.hsaco" % i)
+        q.write_bytes(b"x")
+        os.utime(q, (1000 + i, 1000 + i))
+    assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0, lib.rtpbr_last_error()
+    left = sorted(os.listdir(tmp_path))
+    assert len(left) == 2 and os.path.basename(buf.value.decode()) in left and "old2.hsaco" in left
