@@ -324,6 +324,10 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
 /* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),
  * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
  * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes", "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
+ * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
+ * than the 128 it can hold; a power of two, default 16), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
+ * "sparse_lanes" (same kernel: the object loop is culled per wave with exact Lipschitz bounds while at most this many
+ * lanes march, 0 = never; default 24),
  * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
  * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
  * (default), 2 always), "specialize" (1: use the instance compiled

@@ -513,6 +513,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     P.refill_lanes = c->refill_lanes;
     P.ready_low = c->ready_low;
     P.swap_lanes = c->swap_lanes;
+    P.sparse_lanes = c->sparse_lanes;
     P.mlp_lanes = c->mlp_lanes;
     P.mlp_full = c->mlp_full;
     P.mlp_mfma = c->mlp_mfma;
@@ -524,8 +525,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     {
         // nearest_culled needs |sdf| to be 1-Lipschitz: true for every analytic shape except a cone whose
         // slope vector (scale.x, scale.z) is longer than 1; the rounding allowance scales with the scene
-        float ext = 16.0f;
-        bool ok = c->n_obj <= 8 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
+        // (the camera position counts: camera rays start there)
+        float ext = 16.0f + fabsf(P.cam.lf[0]) + fabsf(P.cam.lf[1]) + fabsf(P.cam.lf[2]);
+        bool ok = c->n_obj <= 8 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED && ext <= 1e12f;
         for (int i = 0; i < c->n_obj; i++) {
             const ObjM& o = c->objm[i];
             const float e = fabsf(o.px) + fabsf(o.py) + fabsf(o.pz) + fabsf(o.sx) + fabsf(o.sy) + fabsf(o.sz);
@@ -616,22 +618,32 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             NEXT_EVENT(c->ev, c->ev_used, a);
             NEXT_EVENT(c->ev, c->ev_used, b);
             HIP_TRY(hipEventRecord(a, c->stream));
-            const bool use_pool = c->scheduler == 1 || (c->scheduler < 0 && P.np >= (1 << 20));
+            // pool scheduler unless asked otherwise: measured faster than one lane per pixel at every frame size from
+            // 256x256 up (profiles/r03_src_*; round 2 switched at 2^20 pixels by a guess)
+            const bool use_pool = c->scheduler != 0;
             if (use_pool) {
-                // pool scheduler: work items are pixels, claimed in chunks by persistent waves
+                // Static strided ownership (persistent_pool_impl): every resident wave owns np / waves pixels.  A wave
+                // holds 128 contexts (64 lanes + 64 slots): when the frame fits (np <= 128 x resident waves) the grid is
+                // sized so that every wave owns <= 128 pixels and keeps them for the whole launch, in whole multiples of
+                // the CU count (every CU the same number of blocks), but never fewer than 64 pixels per wave; larger
+                // frames use every resident wave and walk their pixels in residencies of `residency` bounce-steps.
                 int per_cu = c->jit_mod ? c->jit_mod->persistent_blocks_per_cu : persistent_pool_blocks_per_cu(c->kind);
                 if (per_cu <= 0) per_cu = 2;
-                long long grid = (long long)per_cu * c->n_cu;
-                long long need = ((long long)P.np + 127) / 128;      // 128 contexts per wave
-                need = (need + 3) / 4;
-                if (grid > need) grid = need;
+                if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
+                const long long max_blocks = (long long)per_cu * c->n_cu;
+                long long grid = ((long long)P.np + 511) / 512;                 // 128 contexts per wave, 4 waves per block
+                if (grid >= max_blocks) {
+                    grid = max_blocks;
+                } else {
+                    grid = (grid + c->n_cu - 1) / c->n_cu * c->n_cu;
+                    if (grid > max_blocks) grid = max_blocks;
+                    const long long dense = (long long)P.np / 256;              // >= 64 pixels per wave
+                    if (grid > dense) grid = dense;
+                }
+                if (c->grid_blocks > 0) grid = c->grid_blocks;
                 if (grid < 1) grid = 1;
                 P.total_items = (uint32_t)P.np;
-                long long chunk = (long long)P.np / (grid * 4 * 8);
-                if (chunk < 64) chunk = 64;
-                if (chunk > 1024) chunk = 1024;
-                P.chunk = (uint32_t)chunk;
-                HIP_TRY(hipMemsetAsync(c->work_counter, 0, sizeof(unsigned int), c->stream));
+                P.chunk = (uint32_t)c->residency;                               // bounce-steps per residency (a power of two)
                 if (c->jit_mod) {
                     if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
                 } else
@@ -842,6 +854,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     else if (!strcmp(name, "deposits")) *out = h.deposits + c->deposits_host;
     else if (!strcmp(name, "mlp_wave_evals")) *out = h.mlp_wave_evals;
     else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
+    else if (!strncmp(name, "dbg", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) *out = h.dbg[name[3] - '0'];
     else if (!strcmp(name, "jit_active")) *out = c->jit_mod ? 1 : 0;      // the last sample() ran a run-time compiled instance
     else return fail(RTPBR_EINVAL, "unknown counter %s", name);
     return RTPBR_OK;
@@ -907,6 +920,15 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         // free below 2^32 (work_margin) covers 32 waves per CU x 8192
         if (value < 0 || value > 8192) return fail(RTPBR_EINVAL, "chunk must be 0 (automatic) .. 8192");
         c->chunk = (int)value;
+    } else if (!strcmp(key, "sparse_lanes")) {
+        if (value < 0 || value > 64) return fail(RTPBR_EINVAL, "sparse_lanes must be 0 (never) .. 64");
+        c->sparse_lanes = (int)value;
+    } else if (!strcmp(key, "grid_blocks")) {
+        if (value < 0 || value > 65535) return fail(RTPBR_EINVAL, "grid_blocks must be 0 (automatic) .. 65535");
+        c->grid_blocks = (int)value;
+    } else if (!strcmp(key, "residency")) {
+        if (value < 1 || value > 256 || (value & (value - 1))) return fail(RTPBR_EINVAL, "residency must be a power of two, 1..256");
+        c->residency = (int)value;
     } else if (!strcmp(key, "ready_low")) {
         if (value < 0 || value > 63) return fail(RTPBR_EINVAL, "ready_low must be 0..63");
         c->ready_low = (int)value;

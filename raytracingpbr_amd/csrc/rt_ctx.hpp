@@ -111,11 +111,14 @@ struct rtpbr_ctx {
     int ready_low = 4;
     int jit_waves = 0;            // waves per SIMD the run-time pool kernel is compiled for (0 = as the ahead-of-time instances)
     int chunk = 0;                // work items claimed per atomic by the pool kernels (0 = automatic)
+    int residency = 16;           // src/ form, pool scheduler: bounce-steps a pixel stays resident when a wave owns more pixels than it holds
+    int sparse_lanes = 24;        // src/ form, pool scheduler: wave-culled object loop when at most this many lanes march
+    int grid_blocks = 0;          // src/ form, pool scheduler: workgroups to launch (0 = automatic); tuning / test knob
     int swap_lanes = 8;
     int mlp_lanes = 24;
     int mlp_full = 56;
     int mlp_mfma = 1;
-    int scheduler = -1;  // -1 = auto (pool; persistent form: pool only when there are >= 1M pixels to balance over)
+    int scheduler = -1;  // -1 = auto (the LDS ray pool in both kernel forms), 0 = one lane per item / pixel, 1 = pool
     int waves_per_cu = 0;  // 0 = from the occupancy query
     // timing
     std::vector<hipEvent_t> ev;

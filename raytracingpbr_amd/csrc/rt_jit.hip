@@ -220,7 +220,23 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         if (deterministic) *deterministic = true;
         return rt_fail(RTPBR_ESTATE, "run-time compilation: kernel sources not found next to the library (%s)", dir.c_str());
     }
-    const uint64_t th = baked_hash(key);
+    uint64_t th = baked_hash(key);
+    // RTPBR_JIT_EXTRA_FLAGS: extra compiler arguments (space separated) for experiments and instrumented builds
+    // (e.g. -DRT_DEBUG_PHASE); part of the cache key
+    std::vector<std::string> extra;
+    if (const char* e = getenv("RTPBR_JIT_EXTRA_FLAGS")) {
+        std::string cur;
+        for (const char* q = e;; q++) {
+            if (*q == ' ' || *q == 0) {
+                if (!cur.empty()) extra.push_back(cur);
+                cur.clear();
+                if (!*q) break;
+            } else
+                cur += *q;
+        }
+        for (const std::string& f : extra)
+            for (char ch : f) th = (th ^ (unsigned char)ch) * 1099511628211ull + 1;
+    }
     char name[256];
     snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
              key.cull, key.waves, (unsigned long long)th, (unsigned long long)sh);
@@ -282,6 +298,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
                                      "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-unused-value",
                                      d[0], d[1], d[2], d[3], d[4], d[5], dir + "/rt_jit_tu.hip", "-o", tpath};
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
+    argv.insert(argv.begin() + 10, extra.begin(), extra.end());
     const int rc = run(argv, log);
     struct stat ost;
     const bool have_out = stat(tpath.c_str(), &ost) == 0 && ost.st_size > 0;
@@ -336,6 +353,7 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     char id[224];
     snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
              key.cull, key.waves, (unsigned long long)baked_hash(key));
+    if (const char* e = getenv("RTPBR_JIT_EXTRA_FLAGS")) snprintf(id + strlen(id), sizeof id - strlen(id), "_x%zx", std::hash<std::string>()(e));
     {
         std::unique_lock<std::mutex> lock(g_mu);
         for (;;) {

@@ -859,25 +859,60 @@ RT_D void persistent_steps_impl(const Params& P, int steps) {
         P.ray_buffer[pi] = rb;
         P.image_buffer[pi] = acc;
     }
+#ifdef RT_DEBUG_PHASE
+    {   // the launch's critical path: the pixel with the most (sequential) march steps; and the per-wave maximum, summed
+        atomicMax(&P.counters->dbg[0], (unsigned long long)n_steps);
+        uint32_t m = n_steps;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&P.counters->dbg[1], (unsigned long long)m);
+    }
+#endif
     flush_counters(P, n_steps, n_raycasts, n_hits, n_sky, n_samples, n_dep);
 }
 
 // -------------------------------------------------------------------------------------------
 // src/ persistent-ray form on the LDS ray pool ("persistent-lane
 // scheduler").  Same arithmetic as persistent_steps, but a CONTEXT (one pixel advancing through
-// its `steps` bounce-steps) is decoupled from a lane: contexts whose raycast finished are parked
-// in the wave's LDS slots for shading while the lane takes over a parked context that is ready
-// to march, exactly like trace_paths_pool.  A pixel is owned by one context for the whole launch,
-// so its deposits into image_buffer happen in step order (bit-exact with the sequential form).
-enum { G_OX = 0, G_OY, G_OZ, G_DX, G_DY, G_DZ, G_CR, G_CG, G_CB, G_DEPTH, G_IDX, G_Q, G_S, G_KEY, G_CNT, G_COUNT };
+// bounce-steps) is decoupled from a lane: contexts whose raycast finished are parked in the
+// wave's LDS slots for shading while the lane takes over a parked context that is ready to
+// march, exactly like trace_paths_pool.
+//
+// Ownership is STATIC and STRIDED (round 3; the round-2 kernel claimed chunks of pixels from a global counter and
+// walked each pixel through all `steps` of the launch): wave g of the NW resident waves owns the pixels q = g + k NW,
+// k < n_own.  A context lives as long as `steps` bounce-steps (~25 ms at 256 steps), so with dynamic claiming the
+// launch ended with every wave draining 128 contexts of uniformly staggered progress — waves were resident for only
+// 45 % (768x432) / 61 % (1080p) of the kernel (profiles/r03a_src_*).  Now
+//   * strided ownership gives every wave a statistically identical sample of the frame (sky and object pixels alike):
+//     balanced without a shared queue;
+//   * a wave that owns no more pixels than it has contexts (64 lanes + 64 slots) keeps them all resident for the whole
+//     launch: they advance together and finish within the spread of a 256-term sum;
+//   * a wave that owns more walks them PASS-MAJOR in residencies of S bounce-steps (item i = pass * n_own + k): the
+//     state goes back to ray_buffer after S steps and the slot takes the wave's next item, so all pixels advance
+//     together and the launch drains for the length of ONE residency, not of a whole context.  Item i needs item
+//     i - n_own (the same pixel's previous residency) finished: items are handed out in order and only below
+//     low_water + n_own, low_water = the smallest item still in flight in this wave (recomputed when the hand-out
+//     reaches the bound).  Same wave, same CU: the write-back is visible to the later read without any fence.
+// A pixel is advanced by ONE context at a time and its steps run in order, so its deposits into image_buffer happen
+// in step order (bit-exact with the sequential form) under every ownership / residency choice.
+enum { G_OX = 0, G_OY, G_OZ, G_DX, G_DY, G_DZ, G_CR, G_CG, G_CB, G_DEPTH, G_IDX, G_K, G_S, G_KEY, G_CNT, G_COUNT };
 static_assert(G_COUNT == POOL_WORDS, "pixel-context record must fill the pool record");
 
 struct PixCtx {
     vec3 o, d, col;
     int depth, idx;
-    uint32_t q;
-    int s;
+    uint32_t k;        // the owner wave's k-th pixel: q = wave + k * n_waves
+    int s;             // bounce-step of this launch the context is at
     uint32_t key, cnt;
+};
+
+// wave-uniform constants of the ownership / residency scheme
+struct SrcWave {
+    uint32_t g, nw;        // this wave, resident waves
+    uint32_t n_own;        // pixels owned
+    uint32_t n_items;      // n_own * passes
+    uint32_t s_mask;       // residency length - 1 (a power of two), ~0u when the wave keeps its pixels for the whole launch
+    int lg_s;              // log2(residency length); 31 when single-pass (s >> 31 == 0)
 };
 
 // one iteration of raycast() src/scene.py:59-84 (the ray origin itself moves)
@@ -904,16 +939,55 @@ RT_D void march_step_src(const Params& P, Lane& L) {
     if (done) L.state = hit ? ST_HIT : ST_MISS;
 }
 
+// The same iteration with the object loop culled at wave level (nearest_culled: exact Lipschitz bounds, lb / ub kept by
+// the caller).  Pays when FEW lanes march — a launch ends with every wave marching the handful of pixels whose raycasts
+// graze the ground for hundreds of steps, and those are near ONE object: the other six are skipped for the whole wave.
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void march_step_src_culled(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ > 0 ? NOBJ : 1]) {
+    const bool active = L.state == ST_MARCH;
+    float ld = L.dist;
+    int idx;
+    float dist;
+    nearest_culled<KIND, NOBJ, SIG>(P, L.o, L.t, active, ub, lb, idx, dist);
+    float moved = 0.0f;
+    if (active) {
+        L.idx = idx;
+        L.dist = dist;
+        L.n_steps++;
+        L.steps_left--;
+        bool fb = (L.w > 1.0f) && (ld + dist < L.s);
+        float s_fb = L.s - L.w * L.s;
+        float s_nm = L.w * dist;
+        float s_new = fb ? s_fb : s_nm;
+        L.w = fb ? 1.0f : L.w;
+        L.s = s_new;
+        L.t += s_new;
+        L.o = fma3(s_new, L.d, L.o);
+        bool hit = !fb && (dist < L.t * P.cfg.hit_eps);
+        bool done = (!fb && (hit || L.t >= P.cfg.max_dis)) || L.steps_left == 0;
+        if (done) L.state = hit ? ST_HIT : ST_MISS;
+        // the next evaluation point is |s_new| * |d| away; |d| <= 1 + 2^-20
+        moved = fabs_(s_new) * 1.000001f;
+        ub = dist + moved;
+    }
+#pragma unroll
+    for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
+}
+
 // Advance a context through the part of its step sequence that needs no marching: roulette,
 // deposit + camera-ray regeneration (src/pathtracer.py:53-77).  Returns true when the context
-// is ready to march its next raycast, false when all `steps` are done (state written back).
+// is ready to march its next raycast, false when its residency (or the launch) is over and the
+// state has been written back.  `fresh`: the context was just loaded (X.s is the first step of
+// its residency); otherwise the caller has just completed step X.s - 1.
 template <int KIND>
-RT_D bool pix_advance(const Params& P, PixCtx& X, int steps, uint32_t& n_samples, uint32_t& n_dep) {
+RT_D bool pix_advance(const Params& P, const SrcWave& Wv, PixCtx& X, int steps, bool fresh, uint32_t& n_samples, uint32_t& n_dep) {
     const rtpbr_config& g = P.cfg;
     int px, py;
-    pixel_of(P, X.q, px, py);
+    pixel_of(P, Wv.g + X.k * Wv.nw, px, py);
     const size_t pi = (size_t)px * g.height + py;
-    while (X.s < steps) {
+    for (;;) {
+        if (!fresh && (((uint32_t)X.s & Wv.s_mask) == 0u || X.s >= steps)) break;
+        fresh = false;
         X.key = rng_key(g.seed, (uint32_t)px, (uint32_t)py, P.sample_base + (uint32_t)X.s);
         X.cnt = 0;
         float p = (X.depth == 0) ? 1.0f : g.quality_per_sample;
@@ -949,6 +1023,15 @@ RT_D bool pix_advance(const Params& P, PixCtx& X, int steps, uint32_t& n_samples
     return false;
 }
 
+RT_D uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
 template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
 RT_D void persistent_pool_impl(const Params& P, int steps) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
@@ -964,6 +1047,21 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
     sstate[lane] = SL_EMPTY;
 
+    // ---- what this wave owns and how it walks it (all wave-uniform)
+    SrcWave Wv;
+    Wv.g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wave));
+    Wv.nw = gridDim.x * 4u;
+    const uint32_t np = (uint32_t)P.np;
+    Wv.n_own = np > Wv.g ? (np - Wv.g - 1u) / Wv.nw + 1u : 0u;
+    const uint32_t S = P.chunk;                                   // residency length when the wave owns more than it can hold
+    const bool multi = Wv.n_own > 128u && S < (uint32_t)steps;
+    Wv.s_mask = multi ? S - 1u : 0xffffffffu;
+    Wv.lg_s = multi ? 31 - __builtin_clz(S) : 31;
+    const uint32_t n_pass = multi ? ((uint32_t)steps + S - 1u) >> Wv.lg_s : 1u;
+    Wv.n_items = Wv.n_own * n_pass;
+    uint32_t next_item = 0;                    // items are handed out in order ...
+    uint32_t safe_until = Wv.n_own;            // ... and only below this bound: low_water + n_own (pass 0 needs nothing)
+
     Lane L;
     L.state = ST_IDLE;
     L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
@@ -974,9 +1072,8 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     // bookkeeping of the context being marched
     vec3 a_col = mk(0, 0, 0);
     int a_depth = 0, a_s = 0;
-    uint32_t a_q = 0, a_key = 0, a_cnt = 0;
+    uint32_t a_k = 0, a_key = 0, a_cnt = 0;
     uint32_t n_samples = 0, n_dep = 0;
-    WorkRange wr = {0, 0, false};
     unsigned long long m_ready = 0, m_shade = 0;
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
@@ -992,6 +1089,10 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         l.state = ST_MARCH;
         l.n_raycasts++;
     };
+#ifdef RT_DEBUG_PHASE
+    unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
+    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_sparse_iters = 0;
+#endif
 
     for (;;) {
         // ================================================================ phase B on the slots
@@ -999,21 +1100,39 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             const int n_shade = __popcll(m_shade);
             const int n_ready = __popcll(m_ready);
             const int n_free = 64 - n_shade - n_ready;
-            const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && !wr.drained)));
+            // the hand-out has (nearly) reached its bound: find the oldest item still in flight in this wave (done here,
+            // not inside the pass, so that a wave whose hand-out is blocked by a straggler learns when it has finished)
+            if (multi && safe_until < Wv.n_items && next_item + 64u > safe_until) {
+                uint32_t mine = 0xffffffffu;
+                if (L.state != ST_IDLE) mine = ((uint32_t)a_s >> Wv.lg_s) * Wv.n_own + a_k;
+                if (sstate[lane] != SL_EMPTY) {
+                    const uint32_t it = (pool[G_S][lane] >> Wv.lg_s) * Wv.n_own + pool[G_K][lane];
+                    mine = it < mine ? it : mine;
+                }
+                uint32_t low = wave_min_u32(mine);
+                low = low == 0xffffffffu ? next_item : low;
+                safe_until = (uint32_t)__builtin_amdgcn_readfirstlane((int)(low + Wv.n_own));
+            }
+            const uint32_t limit = Wv.n_items < safe_until ? Wv.n_items : safe_until;
+            const bool run_b = n_shade >= T || (n_ready == 0 && (n_shade > 0 || (n_free > 0 && next_item < limit)));
             if (run_b) {
                 uint32_t st = sstate[lane];
+#ifdef RT_DEBUG_PHASE
+                dbg_passes++;
+                dbg_shaded += (unsigned)n_shade;
+#endif
                 PixCtx X;
                 X.o = X.d = X.col = mk(0, 0, 0);
                 X.depth = X.idx = X.s = 0;
-                X.q = X.key = X.cnt = 0;
-                bool have = false;
+                X.k = X.key = X.cnt = 0;
+                bool have = false, fresh = false;
                 if (st == SL_HIT || st == SL_MISS) {
                     X.o = mk(u2f(pool[G_OX][lane]), u2f(pool[G_OY][lane]), u2f(pool[G_OZ][lane]));
                     X.d = mk(u2f(pool[G_DX][lane]), u2f(pool[G_DY][lane]), u2f(pool[G_DZ][lane]));
                     X.col = mk(u2f(pool[G_CR][lane]), u2f(pool[G_CG][lane]), u2f(pool[G_CB][lane]));
                     X.depth = (int)pool[G_DEPTH][lane];
                     X.idx = (int)pool[G_IDX][lane];
-                    X.q = pool[G_Q][lane];
+                    X.k = pool[G_K][lane];
                     X.s = (int)pool[G_S][lane];
                     X.key = pool[G_KEY][lane];
                     X.cnt = pool[G_CNT][lane];
@@ -1039,34 +1158,45 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     have = true;
                     st = SL_EMPTY;
                 }
-                // free slots take the next pixel of this wave's range
-                uint32_t newq = 0;
-                bool got = claim_items(P, wr, st == SL_EMPTY && !have, lane, newq);
-                if (got) {
-                    int px, py;
-                    if (pixel_of(P, newq, px, py)) {
-                        const size_t pi = (size_t)px * P.cfg.height + py;
-                        bool masked = P.cfg.adaptive_sampling && !(P.diff_pixels[pi] > P.cfg.noise_threshold);
-                        if (!masked) {
-                            rtpbr_ray rb = P.ray_buffer[pi];
-                            X.o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
-                            X.d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
-                            X.col = mk(rb.color[0], rb.color[1], rb.color[2]);
-                            X.depth = rb.depth;
-                            X.q = newq;
-                            X.s = 0;
-                            have = true;
+                // free slots take the wave's next items, in order: the j-th free slot gets item next_item + j
+                {
+                    const bool want = st == SL_EMPTY && !have;
+                    const unsigned long long wm = __ballot(want);
+                    const uint32_t need = (uint32_t)__popcll(wm);
+                    const uint32_t avail = limit - next_item;          // next_item <= limit always
+                    const uint32_t take = need < avail ? need : avail;
+                    const uint32_t rank = (uint32_t)wave_rank(wm);
+                    if (want && rank < take) {
+                        const uint32_t item = next_item + rank;
+                        const uint32_t pass = multi ? item / Wv.n_own : 0u;
+                        const uint32_t k = item - pass * Wv.n_own;
+                        int px, py;
+                        if (pixel_of(P, Wv.g + k * Wv.nw, px, py)) {
+                            const size_t pi = (size_t)px * P.cfg.height + py;
+                            bool masked = P.cfg.adaptive_sampling && !(P.diff_pixels[pi] > P.cfg.noise_threshold);
+                            if (!masked) {
+                                rtpbr_ray rb = P.ray_buffer[pi];
+                                X.o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
+                                X.d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
+                                X.col = mk(rb.color[0], rb.color[1], rb.color[2]);
+                                X.depth = rb.depth;
+                                X.k = k;
+                                X.s = (int)(pass << Wv.lg_s);
+                                have = true;
+                                fresh = true;
+                            }
                         }
                     }
+                    next_item += take;
                 }
                 bool ready = false;
-                if (have) ready = pix_advance<KIND>(P, X, steps, n_samples, n_dep);
+                if (have) ready = pix_advance<KIND>(P, Wv, X, steps, fresh, n_samples, n_dep);
                 if (ready) {
                     pool[G_OX][lane] = f2u(X.o.x); pool[G_OY][lane] = f2u(X.o.y); pool[G_OZ][lane] = f2u(X.o.z);
                     pool[G_DX][lane] = f2u(X.d.x); pool[G_DY][lane] = f2u(X.d.y); pool[G_DZ][lane] = f2u(X.d.z);
                     pool[G_CR][lane] = f2u(X.col.x); pool[G_CG][lane] = f2u(X.col.y); pool[G_CB][lane] = f2u(X.col.z);
                     pool[G_DEPTH][lane] = (uint32_t)X.depth;
-                    pool[G_Q][lane] = X.q;
+                    pool[G_K][lane] = X.k;
                     pool[G_S][lane] = (uint32_t)X.s;
                     pool[G_KEY][lane] = X.key;
                     pool[G_CNT][lane] = X.cnt;
@@ -1078,6 +1208,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             }
         }
 
+        RT_PHASE(tB)
         // ================================================================ dispatch (pool_swap, as in trace_paths_pool)
         {
             const bool is_done = L.state == ST_HIT || L.state == ST_MISS;
@@ -1087,7 +1218,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             rec[G_CR] = f2u(a_col.x); rec[G_CG] = f2u(a_col.y); rec[G_CB] = f2u(a_col.z);
             rec[G_DEPTH] = (uint32_t)a_depth;
             rec[G_IDX] = (uint32_t)L.idx;
-            rec[G_Q] = a_q;
+            rec[G_K] = a_k;
             rec[G_S] = (uint32_t)a_s;
             rec[G_KEY] = a_key; rec[G_CNT] = a_cnt;
             const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
@@ -1097,30 +1228,71 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                 L.d = mk(u2f(rec[G_DX]), u2f(rec[G_DY]), u2f(rec[G_DZ]));
                 a_col = mk(u2f(rec[G_CR]), u2f(rec[G_CG]), u2f(rec[G_CB]));
                 a_depth = (int)rec[G_DEPTH];
-                a_q = rec[G_Q];
+                a_k = rec[G_K];
                 a_s = (int)rec[G_S];
                 a_key = rec[G_KEY]; a_cnt = rec[G_CNT];
                 src_march_init(L);
             }
         }
 
+        RT_PHASE(tD)
         // ================================================================ march
         {
             int n_march = __popcll(__ballot(L.state == ST_MARCH));
             if (n_march == 0) {
                 const bool any_ray = __ballot(L.state != ST_IDLE) != 0;
-                if (!any_ray && m_ready == 0 && m_shade == 0 && wr.drained) break;
+                if (!any_ray && m_ready == 0 && m_shade == 0 && next_item >= Wv.n_items) break;
                 continue;
             }
             const int n_ready = __popcll(m_ready);
             int n_done;
-            do {
-                if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
-                n_march = __popcll(__ballot(L.state == ST_MARCH));
-                n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
-            } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+            bool sparse = false;
+            if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) sparse = P.cull_ok && n_march <= P.sparse_lanes;
+            if (sparse) {
+                if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) {
+                    // few lanes march: cull the object loop for the wave.  The bounds start from "nothing known" (the first
+                    // step evaluates every object, as the plain step does) and live only for this march phase.
+                    float lb[NOBJ];
+#pragma unroll
+                    for (int i = 0; i < NOBJ; i++) lb[i] = -1.0f;
+                    float ub = 3.0e38f;
+                    do {
+#ifdef RT_DEBUG_PHASE
+                        dbg_march_iters++;
+                        dbg_march_lanes += (unsigned)n_march;
+                        dbg_sparse_iters++;
+#endif
+                        march_step_src_culled<KIND, NOBJ, SIG>(P, L, ub, lb);
+                        n_march = __popcll(__ballot(L.state == ST_MARCH));
+                        n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
+                    } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+                }
+            } else {
+                do {
+#ifdef RT_DEBUG_PHASE
+                    dbg_march_iters++;
+                    dbg_march_lanes += (unsigned)n_march;
+#endif
+                    if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
+                    n_march = __popcll(__ballot(L.state == ST_MARCH));
+                    n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
+                } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+            }
         }
+        RT_PHASE(tA)
     }
+#ifdef RT_DEBUG_PHASE
+    if (lane == 0) {   // cycles per phase and wave lifetime (>> 10), passes, slots shaded, march iterations, lanes marching
+        atomicAdd(&P.counters->dbg[0], tB >> 10);
+        atomicAdd(&P.counters->dbg[1], dbg_sparse_iters);      // (march iterations that ran the culled step)
+        atomicAdd(&P.counters->dbg[2], tA >> 10);
+        atomicAdd(&P.counters->dbg[3], (__builtin_readcyclecounter() - t_start) >> 10);
+        atomicAdd(&P.counters->dbg[4], dbg_passes);
+        atomicAdd(&P.counters->dbg[5], dbg_shaded);
+        atomicAdd(&P.counters->dbg[6], dbg_march_iters);
+        atomicAdd(&P.counters->dbg[7], dbg_march_lanes);
+    }
+#endif
     flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, n_dep);
 }
 

@@ -102,6 +102,8 @@ struct Counters {
     unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
     // neural SDF (matrix-core path): MLP passes over a wave, and the ray-evaluations those passes were needed for
     unsigned long long mlp_wave_evals, mlp_lane_evals;
+    // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; "dbg0".."dbg7"
+    unsigned long long dbg[8];
 };
 
 struct Params {
@@ -123,6 +125,7 @@ struct Params {
     int32_t refill_lanes;   // pool scheduler: start new pixel-samples when this many slots are free (or the pool runs dry)
     int32_t ready_low;      // pool scheduler: also shade when no more than this many READY rays are parked
     int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
+    int32_t sparse_lanes;   // src/ pool kernel: cull the object loop per wave when at most this many lanes march (0 = never)
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)

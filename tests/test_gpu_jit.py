@@ -103,15 +103,18 @@ def test_persistent_ray_form_through_run_time_instances(name, tmp_path, monkeypa
     monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     case = case_by_name(name)
     o = OracleRenderer(case.scene, case.cfg); case.run(o)
-    for sched in (0, 1):
+    # (the third setting makes the pool kernel's waves own more pixels than they hold: pass-major residencies of 4 steps)
+    for sched, extra in ((0, {}), (1, {}), (1, {"grid_blocks": 2, "residency": 4})):
         for bake in (0, 1):
             g = Renderer(case.scene, case.cfg)
             g.set_option("jit", 2); g.set_option("jit_bake", bake); g.set_option("scheduler", sched)
+            for k, v in extra.items():
+                g.set_option(k, v)
             case.run(g)
             assert g.counter("jit_active") == 1
-            assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), (sched, bake)
-            assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), (sched, bake)
-            assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels)), (sched, bake)
+            assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), (sched, bake, extra)
+            assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), (sched, bake, extra)
+            assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels)), (sched, bake, extra)
             cg, co = g.counters(), o.counters()
             assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
                    (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits)

@@ -145,7 +145,7 @@ def test_schedule_independence():
                  {"scheduler": 1, "shade_lanes": 1, "swap_lanes": 1}, {"scheduler": 1, "shade_lanes": 64, "swap_lanes": 64},
                  {"scheduler": 1, "shade_lanes": 33, "swap_lanes": 5, "waves_per_cu": 4},
                  {"refill_lanes": 1, "ready_low": 0}, {"refill_lanes": 64, "ready_low": 63}, {"ready_low": 17},
-                 {"chunk": 64}, {"chunk": 1 << 20}, {"chunk": 777, "primary_split": 2},
+                 {"chunk": 64}, {"chunk": 8192}, {"chunk": 777, "primary_split": 2},
                  {"jit": 2, "jit_waves": 7}, {"jit": 2, "jit_bake": 1, "jit_waves": 4, "chunk": 96}, {"refill_lanes": 40, "shade_lanes": 20, "primary_split": 2},
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
                  {"primary_split": 0}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
@@ -222,18 +222,30 @@ def test_persistent_form_schedulers_agree():
     same image_buffer AND the same ray_buffer state, for any launch split."""
     case = case_by_name("src_persistent")
     ref = None
+    # grid_blocks forces waves that own MORE pixels than they hold (5184 pixels: 1 block = 1296 per wave, 9 blocks = 144,
+    # 10 blocks = 130 — a two-item window, the hand-out waits for stragglers all the time), walked in residencies of 1..32
+    # bounce-steps (state through ray_buffer between them); 48 steps with residency 32 ends on a short residency
     for opts, split in (({"scheduler": 0}, (48,)), ({"scheduler": 1}, (48,)), ({"scheduler": 1, "shade_lanes": 9, "swap_lanes": 3}, (5, 43)),
-                        ({"scheduler": 1, "shade_lanes": 64, "swap_lanes": 1, "waves_per_cu": 4}, (24, 24))):
+                        ({"scheduler": 1, "shade_lanes": 64, "swap_lanes": 1, "waves_per_cu": 4}, (24, 24)),
+                        ({"scheduler": 1, "grid_blocks": 1, "residency": 16}, (48,)),
+                        ({"scheduler": 1, "grid_blocks": 1, "residency": 1}, (7, 41)),
+                        ({"scheduler": 1, "grid_blocks": 9, "residency": 32}, (48,)),
+                        ({"scheduler": 1, "grid_blocks": 10, "residency": 4, "shade_lanes": 20}, (48,)),
+                        ({"scheduler": 1, "grid_blocks": 3, "residency": 8, "jit": 0}, (30, 18)),
+                        ({"scheduler": 1, "grid_blocks": 64}, (48,))):
         r = Renderer(case.scene, case.cfg)
         case.setup(r)
         for k, v in opts.items():
             r.set_option(k, v)
+        ctr = [0, 0, 0, 0]
         for n in split:
             r.sample(n)
-        got = (bits(r.image_buffer), bits(r.ray_buffer))
+            c = r.counters()
+            ctr = [ctr[0] + c.samples, ctr[1] + c.raycasts, ctr[2] + c.march_steps, ctr[3] + c.deposits]
+        got = (bits(r.image_buffer), bits(r.ray_buffer), ctr)
         if ref is None:
             ref = got
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), opts
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2], opts
         r.close()
 
 

@@ -28,4 +28,15 @@ print(json.dumps({"W": W, "H": H, "scheduler": sched, "steps": steps, "launches"
                   "raycasts_per_step": round(c.raycasts / c.samples, 4), "march_per_raycast": round(c.march_steps / max(c.raycasts, 1), 3),
                   "hits_per_step": round(c.hits / c.samples, 4), "deposits_per_step": round(c.deposits / c.samples, 4),
                   "jit": r.counter("jit_active")}), flush=True)
+if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
+    d = [r.counter("dbg%d" % i) for i in range(8)]
+    if sched == 0:
+        print(json.dumps({"max_march_steps_of_one_pixel": d[0], "mean_over_waves_of_max_lane": round(d[1] / (W * H / 64), 1),
+                          "mean_march_steps_per_pixel": round(c.march_steps / (W * H), 1)}), flush=True)
+        raise SystemExit
+    waves = max(1, round(W * H / 128 / 4 + 0.5)) * 4
+    print(json.dumps({"phase_Mcycles": {"B": d[0] >> 10, "march": d[2] >> 10, "wave_life_sum": d[3] >> 10},
+                      "passes": d[4], "slots_shaded_per_pass": round(d[5] / max(d[4], 1), 2), "march_iters": d[6], "sparse_iters": d[1],
+                      "lanes_per_march_iter": round(d[7] / max(d[6], 1), 2),
+                      "cycles_per_pass": round((d[0] << 10) / max(d[4], 1)), "cycles_per_march_iter": round((d[2] << 10) / max(d[6], 1))}), flush=True)
 r.close()
