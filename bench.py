@@ -1,32 +1,42 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark of the hot path (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): Cornell Box 1920x1080, 256 spp, 8 bounces, the
-cornell_box_v3 variant of the reference (examples/cornell_box/cornell_box_v3).  One "step" =
-one complete render of that frame: refresh, 256 samples per pixel through the HIP trace
-kernel (+ ordered accumulation), and for N > 1 the single RCCL gather of the per-tile
-radiance to rank 0.  Inputs (scene constants, camera) are resident on the device before the
-timed region.  N ranks share the FIXED frame (tiles dealt round-robin) -> strong scaling.
+Default workload (BASELINE.json configs[1]): Cornell Box 1920x1080, 256 spp, 8 bounces, the cornell_box_v3 variant of
+the reference (examples/cornell_box/cornell_box_v3).  One "step" = one complete render of that frame: refresh, 256
+samples per pixel through the HIP kernels (+ ordered accumulation), and for N > 1 the single RCCL gather of the per-tile
+radiance to rank 0.  Inputs (scene constants, camera, environment) are resident on the device before the timed region.
+N ranks share the FIXED frame (tiles dealt round-robin) -> strong scaling.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is the bound that applies — FP32 vector (VALU) issue: algorithmic
-FLOPs of SURVEY.md §8(d) per launch / the kernels' HIP-event time vs the 157.3 TFLOP/s FP32 vector peak — and carries
-`traffic`, the HBM bytes per launch of the dominant kernel from the committed PMC passes.  `hbm` is the view the
-metric's name asks for: algorithmic bytes (reference layout) and counter-derived bytes per launch / kernel time vs
-8 TB/s — both tiny, this path is branchy scalar FP32.  `cpu_baseline` = the CPU restatement (a port of the reference
-path; Taichi itself is unavailable) timed on this box's host cores on a bounded sample, built -O3 -march=native here.
+Prints ONE JSON line on rank 0.
 
-  --workload c2 (default)  Cornell Box 1920x1080, 256 spp, 8 bounces        (BASELINE.json configs[1], the metric)
-  --workload c5            Cornell Box 7680x4320, 256 spp per step, 8 bounces (configs[4]'s frame: enough pixels per
-                           rank for 8 GPUs; the config's 4096 spp are 16 such progressive steps)
+  --workload c2 (default)  Cornell Box 1920x1080, 256 spp, 8 bounces          (configs[1], the metric)
+  --workload c1            Cornell Box 256x256, 16 spp, 4 bounces             (configs[0])
+  --workload c3            SDF glass bunny 1920x1080, 1024 spp, 16 bounces    (configs[2])
+  --workload c4            Tokyo IBL 3840x2160, 512 spp, 3k env               (configs[3])
+  --workload c5            Cornell Box 7680x4320, 256 spp per step            (configs[4]'s frame; its 4096 spp = 16 steps)
+  --workload src           src/ persistent-ray pipeline 1920x1080, 256 bounce-steps per pixel and step
+
+`roofline` is the bound that applies — FP32 vector (VALU) issue: algorithmic FLOPs of SURVEY.md 8(d) per launch / the
+kernels' HIP-event time vs the 157.3 TFLOP/s FP32 vector peak — and carries `traffic`, the HBM bytes per launch of the
+dominant kernel from the committed PMC passes.  `hbm` is the view the metric's name asks for.  At N = 1 the default
+line also carries `configs`: every other BASELINE config (multi-GPU ones as rank 0's share) and the src/ form, each at
+a bounded sample count with its own FLOP model and roofline fraction; `jit`: what the run-time compiled kernels cost
+at first use and what the same step reaches without them; `cpu_baseline`: the CPU restatement timed on this host.
+
+N > 1: the data path's one collective runs through the product's own C ABI (rtpbr_rccl_init / rtpbr_gather_tiles =
+ncclCommInitRank / ncclGather of ROCm's librccl); torch.distributed (gloo) is only the control plane that ships the
+128-byte id, the barriers and the max-over-ranks time.  --transport torch uses torch.distributed's nccl backend for the
+gather instead; --transport host (functional tests on one device or CPU-side) stages through host tensors.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,22 +51,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "src"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--wait-lanes", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel (src: bounce-steps per pixel) of one step; 0 = the config's")
+    ap.add_argument("--bounces", type=int, default=0)
     ap.add_argument("--scheduler", type=int, default=-1, help="0 = in-register refill, 1 = LDS ray pool (library default)")
-    ap.add_argument("--shade-lanes", type=int, default=0)
-    ap.add_argument("--swap-lanes", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="rtpbr_set_option knob (A/B runs), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config block of the default line")
     ap.add_argument("--no-jit", action="store_true", help="use the ahead-of-time kernels instead of the run-time compiled, scene-specialised ones")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for functional tests)")
-    ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --backend gloo)")
+    ap.add_argument("--keep-jit-cache", action="store_true", help="use the user's code-object cache (default: a fresh one, so that first-use compile time is measured)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "host"],
+                    help="N > 1 gather: rccl = the library's own ncclGather (default), torch = torch.distributed nccl, host = gloo through host memory")
+    ap.add_argument("--backend", default=None, help="(compatibility) nccl = --transport torch, gloo = --transport host")
+    ap.add_argument("--collective-at-1", action="store_true", help="with --gpus 1: still set up a (1-rank) RCCL communicator and run the gather every step")
+    ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --transport host)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.backend == "gloo":
+        a.transport = "host"
+    elif a.backend == "nccl":
+        a.transport = "torch"
+    return a
 
 
 def usable_cores():
@@ -72,7 +89,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sc, cfg, budget_s):
+def cpu_baseline(wl, budget_s):
     """CPU restatement (kind 'port') on the host cores, bounded sample of the same workload.  Timed with the
     -O3 -march=native build of the same source (oracle/Makefile target `fast`, compiled HERE for this host's CPU;
     the exactly-rounded -O2 build stays the parity checker); falls back to the checker build if gcc is missing."""
@@ -88,7 +105,9 @@ def cpu_baseline(sc, cfg, budget_s):
         build = "-O3 -march=native build"
     except Exception:
         pass
-    o = OracleRenderer(sc, cfg, threads=cores)
+    cfg = wl.cfg
+    o = OracleRenderer(wl.scene, cfg, threads=cores)
+    wl.setup(o)
     t0 = time.perf_counter()
     o.sample(1)
     t1 = time.perf_counter() - t0
@@ -97,9 +116,108 @@ def cpu_baseline(sc, cfg, budget_s):
     o.sample(n)
     dt = time.perf_counter() - t0
     samples = cfg.width * cfg.height * n
-    return {"value": round(samples / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{cfg.width}x{cfg.height} x {n} spp, {cfg.max_raytrace} bounces ({samples / 1e6:.1f} Msamples, {dt:.1f} s), "
+    what = "bounce-steps" if wl.family == "src" else "spp"
+    return {"value": round(samples / dt / 1e6, 4), "unit": wl.unit, "cores": cores, "kind": "port",
+            "sample": f"{cfg.width}x{cfg.height} x {n} {what}, MAX_RAYTRACE {cfg.max_raytrace} ({samples / 1e6:.1f} M units, {dt:.1f} s), "
                       f"C restatement of the reference path ({build}) with OpenMP over {cores} threads (Taichi unavailable)"}
+
+
+def make_renderer(wl, device, a, jit=True, bake=True):
+    from raytracingpbr_amd import Renderer
+    r = Renderer(wl.scene, wl.cfg, device=device)
+    wl.setup(r)
+    if a.scheduler >= 0:
+        r.set_option("scheduler", a.scheduler)
+    if jit:
+        # production setting for an offline render of a fixed scene: the kernels compiled at run time for THIS scene and
+        # configuration (rt_jit.hip: ~1-2 s once, then a disk cache), as Taichi JIT-compiles the reference's kernels; falls
+        # back to the ahead-of-time instance if hipcc is not available on the box
+        r.set_option("jit", 1)
+        r.set_option("jit_bake", 1 if bake else 0)
+    else:
+        r.set_option("jit", 0)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        r.set_option(k, int(v))
+    return r
+
+
+def measure(wl, r, steps, warmup, fence=None, gather=None):
+    """W warm-up + K timed steps of one workload on an already configured renderer; returns the wall time and the per-launch
+    figures of the kernels (HIP events recorded on the context's own stream by the library)."""
+    form_src = wl.family == "src"
+
+    def step():
+        r.refresh()
+        r.sample(wl.spp)
+        if gather is not None:
+            gather()
+
+    fence = fence or r.sync
+    for _ in range(warmup):
+        step()
+    fence()
+    trace_ms = primary_ms = 0.0
+    launches = primary_launches = 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        # HIP-event timing of the kernels; reading it waits for the step, which the timed region must wait for anyway
+        tr, _tot, n = r.last_sample_ms()
+        trace_ms += tr
+        launches += n
+        if not form_src:
+            pr, pn = r.last_primary_ms()
+            primary_ms += pr
+            primary_launches += pn
+    fence()
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "trace_ms": trace_ms, "launches": launches, "primary_ms": primary_ms, "primary_launches": primary_launches}
+
+
+def roofline_of(wl, r, m, steps, pixels):
+    """the VALU roofline of one measured workload on this rank: algorithmic FLOPs of the last step / kernel time"""
+    c = r.counters()
+    mlp = r.counter("mlp_lane_evals") if wl.family == "bunny" else 0
+    fpu = wl.flop_per_unit(c, mlp)
+    units_per_step = c.samples
+    kernel_s = (m["trace_ms"] + m["primary_ms"]) / 1e3 / steps
+    tflops = fpu * units_per_step / max(kernel_s, 1e-9) / 1e12
+    return c, fpu, kernel_s, tflops
+
+
+def side_config(name, a, device, rank0_of=1):
+    """one entry of the default line's `configs` block: the named BASELINE config (rank 0's share of a multi-GPU one) at a
+    bounded sample count, with its own FLOP model"""
+    from raytracingpbr_amd import workloads
+    from raytracingpbr_amd.tiles import default_tile
+    bounded = {"c1": 16, "c3": 128, "c4": 256, "c5": 128, "src": 256}[name]
+    wl = workloads.get(name, spp=bounded)
+    r = make_renderer(wl, device, a, jit=not a.no_jit)
+    W, H = wl.cfg.width, wl.cfg.height
+    share = ""
+    if wl.virtual_world > 1:
+        tw, th = default_tile(W, H, wl.virtual_world)
+        r.set_tiles(tw, th, 0, wl.virtual_world)
+        share = f", rank 0 of {wl.virtual_world} ({tw}x{th} tiles dealt round-robin)"
+    if wl.family != "src":
+        r.set_option("reserve_spp", wl.spp)
+    r.sample(1)
+    r.sync()
+    steps = 20 if name == "c1" else 2
+    m = measure(wl, r, steps, 1)
+    c, fpu, kernel_s, tflops = roofline_of(wl, r, m, steps, W * H)
+    units = c.samples * steps
+    out = {"workload": wl.title.replace(f"{workloads.get(name).spp} spp", f"{wl.spp} spp") + share,
+           "value": round(units / m["dt"] / 1e6, 1), "unit": wl.unit, "units_per_step": c.samples, "steps": steps,
+           "ms_per_step": round(m["dt"] / steps * 1e3, 3), "kernel_ms_per_step": round(kernel_s * 1e3, 3),
+           "algorithmic_flop_per_unit": round(fpu), "achieved_tflops": round(tflops, 2), "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+           "raycasts_per_unit": round(c.raycasts / max(c.samples, 1), 3), "march_steps_per_raycast": round(c.march_steps / max(c.raycasts, 1), 2),
+           "run_time_kernels": bool(r.counter("jit_active"))}
+    if wl.family == "bunny":
+        out["mlp_evaluations_per_unit"] = round(r.counter("mlp_lane_evals") / max(c.samples, 1), 2)
+    r.close()
+    return out
 
 
 def main():
@@ -114,54 +232,61 @@ def main():
     dist = None
     if a.same_device:
         local_rank = 0
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if a.backend == "nccl":
+        if a.transport == "torch":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only
+    if not a.keep_jit_cache and "RTPBR_JIT_CACHE" not in os.environ:
+        # a fresh private code-object cache: the first use below then measures the real compile; ranks share it
+        d = [tempfile.mkdtemp(prefix="rtpbr-bench-jit-")] if rank == 0 else [None]
+        if dist is not None:
+            dist.broadcast_object_list(d, src=0)
+        os.environ["RTPBR_JIT_CACHE"] = d[0]
 
-    from raytracingpbr_amd import Config, Renderer, cornell_box
+    from raytracingpbr_amd import workloads
     from raytracingpbr_amd.distributed import TileGather
+    from raytracingpbr_amd.tiles import default_tile
 
-    W, H = {"c2": (1920, 1080), "c5": (7680, 4320)}[a.workload]
-    W, H, SPP = a.width or W, a.height or H, a.spp
-    cfg = Config.cornell_v3(W, H, seed=0, max_raytrace=a.bounces)
-    sc = cornell_box("v3", aspect=W / H)
-    r = Renderer(sc, cfg, device=local_rank)
-    if a.wait_lanes:
-        r.set_option("wait_lanes", a.wait_lanes)
-    if a.scheduler >= 0:
-        r.set_option("scheduler", a.scheduler)
-    if a.shade_lanes:
-        r.set_option("shade_lanes", a.shade_lanes)
-    if a.swap_lanes:
-        r.set_option("swap_lanes", a.swap_lanes)
-    if not a.no_jit:
-        # production setting for an offline render of a fixed scene: the complete-path kernels compiled at run time for
-        # THIS scene and configuration (rt_jit.hip: ~2 s once, then a disk cache), as Taichi JIT-compiles the reference's
-        # kernels; falls back to the ahead-of-time instance if hipcc is not available on the box
-        r.set_option("jit", 1)
-        r.set_option("jit_bake", 1)
-    for kv in a.opt:
-        k, v = kv.split("=")
-        r.set_option(k, int(v))
+    wl = workloads.get(a.workload, a.width, a.height, a.spp, a.bounces)
+    W, H, SPP = wl.cfg.width, wl.cfg.height, wl.spp
     dev = torch.device("cuda", local_rank)
-    # nccl gathers device tensors (RCCL over xGMI); the gloo functional mode stages through the host
-    tg = TileGather(r, rank, world, device=dev if a.backend == "nccl" else None) if world > 1 else None
-    r.set_option("reserve_spp", SPP)     # device buffers are allocated before the timed region, whatever --warmup is
-    r.sample(1)                          # ... and the run-time kernels are compiled / loaded (~1 s the first time) even with --warmup 0
-    r.sync()
+    r = make_renderer(wl, local_rank, a, jit=not a.no_jit)
 
-    def step():
-        r.refresh()
-        r.sample(SPP)
-        if tg is not None:
-            tg.gather()
+    # ---- N > 1: tiles + the one gather
+    gather, multi = None, {}
+    if world > 1 or a.collective_at_1:
+        tw, th = default_tile(W, H, max(world, 2))
+        if a.transport == "rccl":
+            r.set_tiles(tw, th, rank, world)
+            uid = [r.rccl_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)             # 128 bytes over the gloo control plane
+            t0 = time.perf_counter()
+            r.rccl_init(uid[0], rank, world)                       # ncclCommInitRank, ROCm's librccl behind the C ABI
+            r.sync()
+            multi["comm_init_s"] = round(time.perf_counter() - t0, 3)
+            n, rr, ver = r.rccl_info()
+            multi.update({"rccl_nranks": n, "rccl_rank": rr, "rccl_version": ver})
+            gather = r.gather_tiles
+        else:
+            tg = TileGather(r, rank, world, tile=(tw, th), device=dev if a.transport == "torch" else None)
+            gather = tg.gather
+        multi["transport"] = {"rccl": "rtpbr_gather_tiles (ncclGather of ROCm's librccl through the C ABI)",
+                              "torch": "torch.distributed nccl gather", "host": "gloo gather through host memory (functional test)"}[a.transport]
+        multi["tile"] = [tw, th]
+        multi["bytes_gathered_per_rank"] = r.packed_bytes()
+
+    # ---- device buffers and kernels exist before the timed region, whatever --warmup is; the first use is timed
+    if wl.family != "src":
+        r.set_option("reserve_spp", SPP)
+    t0 = time.perf_counter()
+    r.sample(1)
+    r.sync()
+    first_use_s = time.perf_counter() - t0
 
     def fence():
         r.sync()
@@ -170,81 +295,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    trace_ms, launches, primary_ms, primary_launches = 0.0, 0, 0.0, 0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        # HIP-event timing of the dominant kernel (recorded on the context's own stream);
-        # reading it waits for the step, which the timed region must wait for anyway
-        tr, _tot, n = r.last_sample_ms()
-        trace_ms += tr
-        launches += n
-        pr, pn = r.last_primary_ms()
-        primary_ms += pr
-        primary_launches += pn
-    fence()
-    dt = time.perf_counter() - t0
+    gather_ms = []
+
+    def timed_gather():
+        r.sync()                                   # (render done: lets the gather be timed by itself; microseconds)
+        t = time.perf_counter()
+        gather()
+        r.sync()
+        gather_ms.append((time.perf_counter() - t) * 1e3)
+
+    m = measure(wl, r, a.steps, a.warmup, fence, timed_gather if gather is not None else None)
+    dt = m["dt"]
+    render_ms = m["trace_ms"] + m["primary_ms"]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.backend == "nccl" else None)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if a.transport == "torch" else None)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms_per_step": round(render_ms / a.steps, 3),
+                                          "gather_ms_per_step": round(sum(gather_ms[-a.steps:]) / a.steps, 3), "wall_s": round(m["dt"], 4)})
+        multi["per_rank"] = per_rank
 
-    c = r.counters()                                  # this rank, last step
     if rank == 0:
-        total_samples = W * H * SPP * a.steps
-        value = total_samples / dt / 1e6
-        # ---- per-launch figures of the dominant kernel (trace_paths) on this rank
-        avg_launch_s = trace_ms / 1e3 / max(launches, 1)
-        samples_per_launch = c.samples * a.steps / max(launches, 1)
-        k_per_launch = SPP * a.steps / max(launches, 1)
+        c, fpu, kernel_s, tflops = roofline_of(wl, r, m, a.steps, W * H)
+        launches = max(m["launches"], 1)
+        total_units = W * H * SPP * a.steps
+        value = total_units / dt / 1e6
+        # ---- per-launch figures of the dominant kernel on this rank
+        avg_launch_s = m["trace_ms"] / 1e3 / launches
+        k_per_launch = SPP * a.steps / launches
+        units_per_launch = c.samples * a.steps / launches
         sky_frac = c.sky_lookups / max(c.samples, 1)
-        bytes_per_sample = 32.0 / k_per_launch + 12.0 * sky_frac       # SURVEY.md §8(d), reference layout
-        alg_bytes = bytes_per_sample * samples_per_launch
-        achieved_gbs = alg_bytes / avg_launch_s / 1e9
-        B = c.raycasts / max(c.samples, 1)
-        S = c.march_steps / max(c.raycasts, 1)
-        flop_per_sample = 110.0 + B * (S * 338.0 + 197.0 + 110.0 + 25.0) + sky_frac * 15.0   # §8(d) Cornell figures
-        # the march/shade arithmetic is spread over primary_rays (camera rays) and the trace kernel
-        path_s = (trace_ms + primary_ms) / 1e3 / max(launches, 1)
-        achieved_tflops = flop_per_sample * samples_per_launch / path_s / 1e12
+        if wl.family == "src":      # SURVEY 8(d), src form, per bounce-step: T6 R+W once per launch, 32 B per deposit, 12 B per sky lookup
+            bytes_per_unit = 80.0 / k_per_launch + 32.0 * c.deposits / max(c.samples, 1) + 12.0 * sky_frac
+        else:                       # examples form, K spp per launch: T7 R+W per pixel and launch + one texel per escaping path
+            bytes_per_unit = 32.0 / k_per_launch + 12.0 * sky_frac
+        alg_bytes = bytes_per_unit * units_per_launch
+        achieved_gbs = alg_bytes / max(avg_launch_s, 1e-9) / 1e9
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside
         # this process); only reported when it was measured on this very workload
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
             w = tj["workload"]
-            if (w["width"], w["height"], w["spp"], w["bounces"]) == (W, H, SPP, a.bounces) and world == 1 \
+            if a.workload == "c2" and (w["width"], w["height"], w["spp"], w["bounces"]) == (W, H, SPP, wl.cfg.max_raytrace) and world == 1 \
                     and abs(w["spp_per_launch"] - k_per_launch) < 1e-6:
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except Exception:
             pass
         jit_on = bool(r.counter("jit_active"))
-        kname, pname = ("rt_jit_trace", "rt_jit_primary") if jit_on else ("trace_paths_pool", "primary_rays")
+        if wl.family == "src":
+            kname, pname = ("rt_jit_persistent_pool" if jit_on else "persistent_pool"), None
+        else:
+            kname, pname = ("rt_jit_trace", "rt_jit_primary") if jit_on else ("trace_paths_pool", "primary_rays")
+            if m["primary_launches"] == 0:
+                pname = None
+        what = "bounce-steps per pixel" if wl.family == "src" else "spp"
         out = {
-            "metric": f"Msamples/sec (pixels x spp / s), Cornell Box {W}x{H}",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": f"{wl.unit.replace('/s', '')}/sec (pixels x {what} / s), {wl.short} {W}x{H}",
+            "value": round(value, 2), "unit": wl.unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell Box (cornell_box_v3 variant) {W}x{H}, {SPP} spp, {a.bounces} bounces, "
-                                   f"seed 0; one step = refresh + {SPP} spp trace + ordered accumulation"
+            "config": {"workload": f"{wl.title}; one step = refresh + {SPP} {what} through the sample kernels"
+                                   + ("" if wl.family == "src" else " + ordered accumulation")
                                    + (f" + 1 RCCL gather of {world} tile sets" if world > 1 else ""),
                        "parallelism": f"tiles{world}" if world > 1 else "single",
                        "kernels": "run-time compiled for this scene (object table and render configuration baked)" if jit_on
                                   else "ahead-of-time instances",
-                       "raycasts_per_sample": round(B, 3), "march_steps_per_raycast": round(S, 3)},
+                       "raycasts_per_unit": round(c.raycasts / max(c.samples, 1), 3),
+                       "march_steps_per_raycast": round(c.march_steps / max(c.raycasts, 1), 3)},
             # the binding roofline: FP32 vector issue.  achieved = algorithmic FLOPs per launch / HIP-event time of the
-            # kernels that do them (primary_rays + trace_paths_pool); traffic = HBM bytes per launch of the dominant kernel
-            "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches_timed": launches,
-                         "kernels": f"{pname} + {kname}",
-                         "primary_rays_avg_launch_ms": round(primary_ms / max(primary_launches, 1), 3),
-                         "primary_rays_launches_timed": primary_launches,
-                         "algorithmic_flop_per_sample": round(flop_per_sample),
-                         "note": "branchy scalar FP32 on the vector ALU (no MFMA in this scene); peak = 157.3 TFLOP/s FP32 vector"},
+            # kernels that do them; traffic = HBM bytes per launch of the dominant kernel
+            "roofline": {"bound": "valu", "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / VALU_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kname, "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches_timed": m["launches"],
+                         "kernels": f"{pname} + {kname}" if pname else kname,
+                         "primary_rays_avg_launch_ms": round(m["primary_ms"] / max(m["primary_launches"], 1), 3),
+                         "primary_rays_launches_timed": m["primary_launches"],
+                         "algorithmic_flop_per_unit": round(fpu),
+                         "note": "branchy scalar FP32 on the vector ALU; peak = 157.3 TFLOP/s FP32 vector"
+                                 + (" (the neural SDF's f32 MFMA has the same peak rate and does not overlap with VALU work)" if wl.family == "bunny" else "")},
             # the view the metric's name asks for: HBM GB/s of the dominant kernel vs 8 TB/s
             "hbm": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "achieved_algorithmic": round(achieved_gbs, 4), "frac_algorithmic": round(achieved_gbs / HBM_PEAK_GBS, 8),
@@ -253,8 +383,34 @@ def main():
                     "frac_counters": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                     "traffic": traffic, "kernel": kname},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, cfg, a.cpu_seconds)
+        if wl.family != "src":
+            split = m["primary_launches"] > 0
+            out["staging"] = {"bytes_per_step": int((16 + (8 if split else 0)) * c.samples),
+                              "note": "transient device memory of one step: one float4 per pixel-sample (+ one float2 primary record), "
+                                      "reduced in sample order into image_buffer; reserved before the timed region (option reserve_spp)"}
+        if multi:
+            out["multi_gpu"] = multi
+        r.close()
+        if world == 1:
+            # ---- what the run-time compiled kernels cost and buy (same workload, one step each)
+            jit = {"first_use_s": round(first_use_s, 3),
+                   "first_use_note": "first rtpbr_sample(1): hipcc --genco of the scene's kernels into a fresh cache + module load + staging touch"
+                                     if not a.keep_jit_cache else "first rtpbr_sample(1) with the user's cache"}
+            if not a.no_jit and not a.no_configs:
+                for key, (j, b) in (("unbaked_value", (True, False)), ("aot_value", (False, False))):
+                    r2 = make_renderer(wl, local_rank, a, jit=j, bake=b)
+                    if wl.family != "src":
+                        r2.set_option("reserve_spp", SPP)
+                    r2.sample(1)
+                    r2.sync()
+                    m2 = measure(wl, r2, 1, 0)
+                    jit[key] = round(W * H * SPP / m2["dt"] / 1e6, 1)
+                    r2.close()
+            out["jit"] = jit
+            if a.workload == "c2" and not a.no_configs:
+                out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c4", "c5", "src")}
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

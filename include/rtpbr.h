@@ -306,6 +306,9 @@ int rtpbr_rccl_init(rtpbr_ctx* ctx, const void* unique_id, size_t nbytes, int ra
 int rtpbr_rccl_init_all(rtpbr_ctx** ctxs, int n);
 int rtpbr_gather_tiles(rtpbr_ctx* ctx);
 int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n);
+/* What RCCL itself reports for this context's communicator: ncclCommCount (rccl.h:378), ncclCommUserRank (:400) and the
+ * library's version (ncclGetVersion, :164) — so that a caller can show that the collective really spans `world` ranks. */
+int rtpbr_rccl_info(rtpbr_ctx* ctx, int* nranks, int* rank, int* version);
 
 /* Measurement hooks (SURVEY.md §5 tracing row, §8(d)). */
 int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking */

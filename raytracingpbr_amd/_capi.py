@@ -24,7 +24,7 @@ ENTRY_POINTS = [
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",
     "read_buffer", "write_buffer", "packed_bytes", "pack_tiles", "unpack_tiles",
     "get_counters", "get_counter", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
-    "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all",
+    "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info",
 ]
 
 
@@ -35,7 +35,7 @@ class RtpbrError(RuntimeError):
 
 
 class CApi:
-    def __init__(self, path, prefix="rtpbr_", optional=("test_math", "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all")):
+    def __init__(self, path, prefix="rtpbr_", optional=("test_math", "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info")):
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} not found — build it first (python -c 'import __graft_entry__ as g; g.build()')")
@@ -74,6 +74,7 @@ class CApi:
             "rccl_init_all": (C.c_int, [C.POINTER(p), C.c_int]),
             "gather_tiles": (C.c_int, [p]),
             "gather_tiles_all": (C.c_int, [C.POINTER(p), C.c_int]),
+            "rccl_info": (C.c_int, [p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "test_math": (C.c_int, [p, C.c_int, p, p, p, p, C.c_int]),
         }
         self.fn = {}

@@ -37,6 +37,9 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 Rccl g_rccl;
 
@@ -62,6 +65,9 @@ int load_rccl() {
     RT_SYM(GroupEnd, "ncclGroupEnd");
     RT_SYM(GetErrorString, "ncclGetErrorString");
     RT_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
+    RT_SYM(CommCount, "ncclCommCount");
+    RT_SYM(CommUserRank, "ncclCommUserRank");
+    RT_SYM(GetVersion, "ncclGetVersion");
 #undef RT_SYM
     g_rccl.h = h;
     return RTPBR_OK;
@@ -202,6 +208,19 @@ extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
     if (rc != RTPBR_OK) return rc;
     for (int i = 0; i < n; i++)
         if (int r = enqueue_unpack(ctxs[i])) return r;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_rccl_info(rtpbr_ctx* c, int* nranks, int* rank, int* version) {
+    if (!c) return rt_fail(RTPBR_EINVAL, "null ctx");
+    if (!c->comm) return rt_fail(RTPBR_ESTATE, "rtpbr_rccl_init first");
+    int n = 0, r = 0, v = 0;
+    NCCL_TRY(g_rccl.CommCount((ncclComm_t)c->comm, &n));
+    NCCL_TRY(g_rccl.CommUserRank((ncclComm_t)c->comm, &r));
+    NCCL_TRY(g_rccl.GetVersion(&v));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (version) *version = v;
     return RTPBR_OK;
 }
 

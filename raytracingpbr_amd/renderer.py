@@ -206,6 +206,12 @@ class Renderer:
         """collective: pack -> one ncclGather to rank 0 -> rank 0 unpacks, on this context's stream"""
         self.api.call("gather_tiles", self._ctx)
 
+    def rccl_info(self):
+        """(ranks in this context's communicator, its rank, RCCL version) as RCCL reports them"""
+        n, r, v = C.c_int(), C.c_int(), C.c_int()
+        self.api.call("rccl_info", self._ctx, C.byref(n), C.byref(r), C.byref(v))
+        return n.value, r.value, v.value
+
     def stream(self) -> int:
         s = C.c_void_p()
         self.api.call("get_stream", self._ctx, C.byref(s))

@@ -352,6 +352,9 @@ def test_error_channel():
         r.sample(1)                                      # env-map sky without an env map
     with pytest.raises(RtpbrError):
         r.set_option("no_such_option", 1)
+    for key, value in (("chunk", 8193), ("residency", 12), ("residency", 512), ("sparse_lanes", 65), ("grid_blocks", -1)):
+        with pytest.raises(RtpbrError):                  # out of range (chunk: the 32-bit work counter's overshoot margin)
+            r.set_option(key, value)
     with pytest.raises(ValueError):
         r.image_buffer = np.zeros((3, 3, 4), np.float32)
     # a rejected scene leaves the context as it was
@@ -406,27 +409,48 @@ def test_full_size_cornell_1080p():
     assert np.all(np.isfinite(g.image_pixels)) and g.image_pixels.min() >= 0 and g.image_pixels.max() <= 1
 
 
-def test_bench_multirank_path_functional(tmp_path):
-    """bench.py's N>1 path (tile partition + one gather + max-over-ranks timing), exercised with
-    2 ranks sharing this box's single GPU over gloo: the RCCL collective itself needs 2 GPUs, but
-    everything around it (launch via torch.distributed.run, TileGather, JSON contract) runs."""
+def _run_bench(args, nproc=0, timeout=900):
     import json
     import os
     import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--width", "480", "--height", "270", "--spp", "16", "--backend", "gloo", "--same-device", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    cmd = [sys.executable]
+    if nproc:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    out = subprocess.run(cmd + [os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.split("\n") if l.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["unit"] == "Msamples/s"
-    for k in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+    return json.loads([l for l in out.stdout.split("\n") if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5", "src"])
+def test_bench_multirank_path_functional(workload):
+    """bench.py's N>1 path (tile partition + one gather + max-over-ranks timing) under torch.distributed.run, exercised with
+    2 ranks sharing this box's single GPU and the gather staged through host memory: the RCCL collective itself needs 2
+    GPUs, but everything around it (launch, control plane, tiles, per-rank report, JSON contract) runs."""
+    j = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--workload", workload, "--width", "480", "--height", "270", "--spp", "16",
+                    "--transport", "host", "--same-device", "--no-cpu-baseline"], nproc=2)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["unit"] == ("Mbounce-steps/s" if workload == "src" else "Msamples/s")
+    for k in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "multi_gpu"):
         assert k in j
+    mg = j["multi_gpu"]
+    assert [p["rank"] for p in mg["per_rank"]] == [0, 1] and all(p["kernel_ms_per_step"] > 0 for p in mg["per_rank"])
+    assert mg["bytes_gathered_per_rank"] > 0 and "host" in mg["transport"]
+
+
+def test_bench_default_transport_is_the_c_abi_rccl_gather():
+    """The transport a SCALE run takes by default — rtpbr_rccl_unique_id / rccl_init / gather_tiles, i.e. ROCm's librccl
+    behind the C ABI — driven by bench.py itself on this box's one GPU (a 1-rank communicator): RCCL reports the rank
+    count, the set-up time is in the line and it is seconds, not minutes."""
+    j = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--width", "480", "--height", "270", "--spp", "16",
+                    "--collective-at-1", "--no-cpu-baseline", "--no-configs"])
+    mg = j["multi_gpu"]
+    assert mg["rccl_nranks"] == 1 and mg["rccl_rank"] == 0 and mg["rccl_version"] > 20000
+    assert mg["comm_init_s"] < 60 and "ncclGather" in mg["transport"]
+    assert j["jit"]["first_use_s"] > 0 and j["roofline"]["frac"] > 0
 
 
 def test_gathered_frame_equals_single_gpu_frame():
