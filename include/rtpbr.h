@@ -202,6 +202,9 @@ typedef struct rtpbr_config {
      * only while its running mean display-space change diff_pixels exceeds noise_threshold */
     int32_t  adaptive_sampling;
     float    noise_threshold;
+    /* neural-bunny animation: amplitude of the vertical bob p.z += anim_bob * sin(t) after the frame rotation
+     * (bunny_sdf_glass.py:216 and bunny_sdf_v2.py:216: 0.1; bunny_sdf.py:213-214 rotates only: 0) */
+    float    anim_bob;
 } rtpbr_config;
 
 /* ------------------------------------------------------------------ buffers */

@@ -6,12 +6,16 @@
  * (raytracingpbr_amd/) may import, link or call it.  Allowed users: tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg.
  *
- * PARITY PIN STATUS: the reference has no tests, no golden vectors and cannot be executed
- * here (Taichi is not installed, its RNG stream is scheduler dependent — SURVEY.md §8(c),
- * Appendix D1).  This oracle is therefore pinned by (K1) analytic known answers for every
- * deterministic function, (K3) block means of the one committed result image that belongs
- * to a known variant (others/cornell_box_taichi.png ~ cornell_box_v2.py, tolerance 0.06),
- * and nothing stronger: "parity unpinned" beyond that.
+ * PARITY PIN STATUS: pinned to the reference's own code, at rounding tolerance.  Taichi is not installable here and
+ * the reference ships no tests or golden vectors, so the pin is: (P1) the reference's own
+ * @ti.func / @ti.kernel bodies, imported from /root/reference and executed on a stand-in runtime by
+ * tools/ref_crosscheck.py, whose inputs and outputs are the fixtures tests/golden/ref_*.npz that
+ * tests/test_oracle_refpin.py compares this file with — function tables, per-raycast and per-interaction
+ * observations, per-sample colours and counts, frame buffers; every sample that differs is traced to a decision whose
+ * operands agree to a stated number of ulps (the decision log below) or the test fails; (P2) the reference's committed
+ * Cornell image per pixel on the GPU, (P3) the published bunny image's silhouette; (K1) analytic known answers.
+ * What the stand-in cannot show — Taichi's own lowering of ti.random, casts and min/max of NaN — is listed in
+ * SURVEY.md Appendix D and DESIGN.md section 2.
  *
  * Each function cites the reference lines it follows (paths relative to the reference
  * root).  Numerics: IEEE f32, operation order as written, see rt_oracle_math.h.
@@ -29,12 +33,65 @@
 static __thread char g_err[256];
 static int fail(int code, const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); return code; }
 
+/* ------------------------------------------------------------------ decision log (test hook)
+ * Every data-dependent branch of the sample path goes through DEC(kind, a, b, scale) = (a < b).  While a log is
+ * active on this thread (rto_test_sample_decisions) the operands are recorded, and the decisions whose ordinal is in
+ * the flip list return the opposite: tests/test_oracle_refpin.py uses this to show that a sample which differs from
+ * the reference's own run differs by a decision whose operands were within a few ulps of `scale` (the magnitude of
+ * the largest intermediate that went into them), and that taking that decision the other way reproduces the
+ * reference.  EVENT entries mark what happened (end of a raycast, of a surface interaction) so that a log can be
+ * lined up with the reference's recorded events.  The -O3 timing build (make fast) compiles the hook out. */
+enum { RTO_D_NEAREST = 1, RTO_D_HIT, RTO_D_FALLBACK, RTO_D_ESCAPE, RTO_D_OUTER, RTO_D_REFLECT, RTO_D_TIR, RTO_D_TRANSMIT,
+       RTO_D_HORIZON, RTO_D_STOP_GAIN, RTO_D_STOP_LO, RTO_D_STOP_HI, RTO_D_ROULETTE, RTO_D_ENV_X, RTO_D_ENV_Y, RTO_D_BOUND,
+       RTO_E_RAYCAST = 100, RTO_E_SURFACE = 101, RTO_E_DIR = 102 };
+typedef struct { int kind, outcome; float a, b, scale; } rto_decision;
+#ifndef RTO_NO_DECISIONS
+static __thread struct { int active, n, cap, n_flip; const int* flip; rto_decision* log; } g_dec;
+/* surface-interaction outputs to adopt instead of the computed ones (rows of 10 floats: direction, colour, origin, draw
+ * count), by ordinal within the sample: lets a test keep the oracle on the reference's recorded trajectory, so that what
+ * is compared downstream is not the amplification of an upstream rounding difference (tests/test_oracle_refpin.py) */
+static __thread struct { const float* rows; int n, next; } g_inj;
+static int dec_slow(int kind, float a, float b, float scale, int r) {
+    const int i = g_dec.n++;
+    for (int k = 0; k < g_dec.n_flip; k++) if (g_dec.flip[k] == i) r = !r;
+    if (g_dec.log && i < g_dec.cap) { rto_decision d = {kind, r, a, b, scale}; g_dec.log[i] = d; }
+    return r;
+}
+static inline int DEC(int kind, float a, float b, float scale) {
+    const int r = a < b;
+    return __builtin_expect(g_dec.active, 0) ? dec_slow(kind, a, b, scale, r) : r;
+}
+/* floor(v) for a texel index; a flip moves to the other side of the nearest integer boundary */
+static inline int DEC_FLOOR(int kind, float v, float scale) {
+    int x = (int)v;
+    if (__builtin_expect(g_dec.active, 0)) {
+        const float fr = v - (float)x;
+        const float edge = fr < 0.5f ? (float)x : (float)(x + 1);
+        if (!dec_slow(kind, v, edge, scale, 1)) x = fr < 0.5f ? x - 1 : x + 1;
+    }
+    return x;
+}
+static inline void EVENT(int kind, float a, float b, float c) {
+    if (__builtin_expect(g_dec.active, 0) && g_dec.log && g_dec.n < g_dec.cap) {
+        rto_decision d = {kind, 0, a, b, c};
+        g_dec.log[g_dec.n] = d;
+    }
+    if (g_dec.active) g_dec.n++;
+}
+#else
+#define DEC(kind, a, b, scale) ((void)(scale), (a) < (b))
+#define DEC_FLOOR(kind, v, scale) ((void)(scale), (int)(v))
+#define EVENT(kind, a, b, c) ((void)(a), (void)(b), (void)(c))
+#endif
+static inline float v3_maxabs(v3 p) { return fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fabsf(p.z)); }
+
 struct rto_ctx {
     rtpbr_config cfg;
     int have_cfg, have_scene, have_cam;
     rtpbr_object obj[RTPBR_MAX_OBJECTS];
     int n_obj;
     rtpbr_camera cam;
+    float extent;                         /* max_i(|centre_i| + |size_i|), inf-norm: magnitude of the SDF intermediates (decision log) */
     float* env; int env_w, env_h;         /* T9: (W_e,H_e,3) f32, [x][y] */
     float* image_buffer;                  /* T7 */
     float* image_pixels;                  /* T8 */
@@ -117,7 +174,7 @@ static v3 to_local(const struct rto_ctx* c, const rtpbr_object* o, v3 p) {
         rto_sincosf(t, &st, &ct);
         /* angle(vec3(0,0,t)) = [[c,s,0],[-s,c,0],[0,0,1]] */
         v3 r = v3_make(fmaf(st, l.y, ct * l.x), fmaf(ct, l.y, -st * l.x), l.z);
-        r.z = r.z + 0.1f * st;
+        r.z = r.z + c->cfg.anim_bob * st;      /* bunny_sdf_glass.py:216, bunny_sdf_v2.py:216 (0.1); bunny_sdf.py has no bob (0) */
         l = r;
     }
     return l;
@@ -138,7 +195,7 @@ static int nearest(struct rto_ctx* c, v3 p, float* dist, rtpbr_counters* ctr) {
     else { best = fabsf(signed_distance(c, &c->obj[0], p)); start = 1; }
     for (int i = start; i < c->n_obj; i++) {
         float d = fabsf(signed_distance(c, &c->obj[i], p));
-        if (d < best) { best = d; idx = i; }
+        if (DEC(RTO_D_NEAREST, d, best, v3_maxabs(p) + c->extent)) { best = d; idx = i; }
     }
     ctr->march_steps++;
     *dist = best;
@@ -152,16 +209,18 @@ typedef struct { v3 origin, direction, color; int depth; } ray_t;
 /* examples, plain: cornell_box_v2.py:186-196, cornell_box.py:213-223, shortest:63-72 */
 static int raycast_plain(struct rto_ctx* c, const ray_t* ray, v3* pos, int* hit, rtpbr_counters* ctr) {
     float t = c->cfg.min_dis;
-    int idx = 0; *hit = 0; *pos = ray->origin;
+    int idx = 0, steps = 0; *hit = 0; *pos = ray->origin;
     for (int i = 0; i < c->cfg.max_raymarch; i++) {
         float d;
         *pos = v3_fma(t, ray->direction, ray->origin);
         idx = nearest(c, *pos, &d, ctr);
         t += d;
-        *hit = d < c->cfg.hit_eps;
-        if (t > c->cfg.max_dis || *hit) break;
+        steps = i + 1;
+        *hit = DEC(RTO_D_HIT, d, c->cfg.hit_eps, v3_maxabs(*pos) + c->extent);
+        if (DEC(RTO_D_ESCAPE, c->cfg.max_dis, t, t) || *hit) break;
     }
     ctr->raycasts++;
+    EVENT(RTO_E_RAYCAST, (float)*hit, (float)steps, (float)idx);
     return idx;
 }
 
@@ -170,14 +229,16 @@ static int raycast_plain(struct rto_ctx* c, const ray_t* ray, v3* pos, int* hit,
 static int raycast_relaxed(struct rto_ctx* c, const ray_t* ray, v3* pos, int* hit, rtpbr_counters* ctr) {
     float t = c->cfg.min_dis;
     float w = c->cfg.omega0, s = 0.0f, d = 0.0f;
-    int idx = 0; *hit = 0; *pos = ray->origin;
+    int idx = 0, steps = 0; *hit = 0; *pos = ray->origin;
     for (int i = 0; i < c->cfg.max_raymarch; i++) {
         float dist;
         *pos = v3_fma(t, ray->direction, ray->origin);
         idx = nearest(c, *pos, &dist, ctr);
+        steps = i + 1;
         float ld = d;
         d = dist;
-        if ((!c->cfg.omega_guard || w > 1.0f) && ld + d < s) {
+        const float mag = v3_maxabs(*pos) + c->extent;
+        if ((!c->cfg.omega_guard || w > 1.0f) && DEC(RTO_D_FALLBACK, ld + d, s, mag)) {
             s -= w * s;
             t += s;
             w = c->cfg.omega_fb_a + c->cfg.omega_fb_b * w;
@@ -186,21 +247,24 @@ static int raycast_relaxed(struct rto_ctx* c, const ray_t* ray, v3* pos, int* hi
         float err = d / t;
         s = w * d;
         t += s;
-        *hit = err < c->cfg.hit_eps;
-        if (t > c->cfg.max_dis || *hit) break;
+        *hit = DEC(RTO_D_HIT, err, c->cfg.hit_eps, mag / (t - s));      /* |d - t eps| in units of the position's rounding */
+        if (DEC(RTO_D_ESCAPE, c->cfg.max_dis, t, t) || *hit) break;
     }
     ctr->raycasts++;
+    EVENT(RTO_E_RAYCAST, (float)*hit, (float)steps, (float)idx);
     return idx;
 }
 
 /* src/scene.py:59-84: the ray origin itself moves, hit = d < t*PIXEL_RADIUS, depth += 1 */
 static int raycast_src(struct rto_ctx* c, ray_t* ray, int* hit, rtpbr_counters* ctr) {
     float t = 0.0f, w = c->cfg.omega0, s = 0.0f, d = c->cfg.max_dis;
-    int idx = 0; *hit = 0;
+    int idx = 0, steps = 0; *hit = 0;
     for (int i = 0; i < c->cfg.max_raymarch; i++) {
         float ld = d;
         idx = nearest(c, ray->origin, &d, ctr);
-        if (w > 1.0f && ld + d < s) {
+        steps = i + 1;
+        const float mag = v3_maxabs(ray->origin) + c->extent;
+        if (w > 1.0f && DEC(RTO_D_FALLBACK, ld + d, s, mag)) {
             s -= w * s;
             w = 1.0f;
             t += s;
@@ -210,9 +274,10 @@ static int raycast_src(struct rto_ctx* c, ray_t* ray, int* hit, rtpbr_counters* 
         s = w * d;
         t += s;
         ray->origin = v3_fma(s, ray->direction, ray->origin);
-        *hit = d < t * c->cfg.hit_eps;
-        if (*hit || t >= c->cfg.max_dis) break;
+        *hit = DEC(RTO_D_HIT, d, t * c->cfg.hit_eps, mag);
+        if (*hit || !DEC(RTO_D_ESCAPE, t, c->cfg.max_dis, t)) break;
     }
+    EVENT(RTO_E_RAYCAST, (float)*hit, (float)steps, (float)idx);
     ray->depth += 1;
     ctr->raycasts++;
     return idx;
@@ -271,10 +336,12 @@ static void surface_interaction(struct rto_ctx* c, ray_t* ray, const rtpbr_objec
         ray->direction = hemispheric_sampling(n, key, cnt);
         ray->color = v3_mul(ray->color, albedo);
         ray->origin = pos;
+        EVENT(RTO_E_SURFACE, (float)*cnt, 0.0f, 0.0f);
+        EVENT(RTO_E_DIR, ray->direction.x, ray->direction.y, ray->direction.z);
         return;
     }
     v3 I = ray->direction;
-    int outer = v3_dot(I, n) < 0.0f;
+    int outer = DEC(RTO_D_OUTER, v3_dot(I, n), 0.0f, 1.0f);
     if (!outer) n = v3_neg(n);
     v3 hemi = hemispheric_sampling(n, key, cnt);
     float alpha = m->roughness * m->roughness;
@@ -290,16 +357,16 @@ static void surface_interaction(struct rto_ctx* c, ray_t* ray, const rtpbr_objec
     if (g->fresnel_roughness_mix) F = rto_mix(F, F0, m->roughness);
     v3 D;
     float c1 = rto_rand(key, cnt);
-    if (c1 < F + m->metallic || k < 0.0f) {
+    if (DEC(RTO_D_REFLECT, c1, F + m->metallic, 1.0f) || DEC(RTO_D_TIR, k, 0.0f, 1.0f)) {
         float tn = 2.0f * NoI;
         D = v3_make(I.x - tn * N.x, I.y - tn * N.y, I.z - tn * N.z);
         if (g->below_horizon == RTPBR_HORIZON_KILL) {
-            float keep = v3_dot(D, n) > 0.0f ? 1.0f : 0.0f;
+            float keep = DEC(RTO_D_HORIZON, 0.0f, v3_dot(D, n), 1.0f) ? 1.0f : 0.0f;
             ray->color = v3_scale(ray->color, keep);
-        } else if (v3_dot(D, n) < 0.0f) D = v3_neg(D);
+        } else if (DEC(RTO_D_HORIZON, v3_dot(D, n), 0.0f, 1.0f)) D = v3_neg(D);
     } else {
         float c2 = rto_rand(key, cnt);
-        if (c2 < m->transmission) {
+        if (DEC(RTO_D_TRANSMIT, c2, m->transmission, 1.0f)) {
             float f = sqrtf(k) + eta * NoI;
             D = v3_make(eta * I.x - f * N.x, eta * I.y - f * N.y, eta * I.z - f * N.z);
         } else D = hemi;
@@ -308,10 +375,21 @@ static void surface_interaction(struct rto_ctx* c, ray_t* ray, const rtpbr_objec
     ray->color = v3_mul(ray->color, albedo);
     if (g->origin_mode == RTPBR_ORIGIN_HIT) ray->origin = pos;
     else {
-        float sgn = v3_dot(D, n) < 0.0f ? -1.0f : 1.0f;
+        float sgn = DEC(RTO_D_HORIZON, v3_dot(D, n), 0.0f, 1.0f) ? -1.0f : 1.0f;
         v3 off = v3_scale(v3_scale(n, g->min_dis), sgn);
         ray->origin = v3_add(ray->origin, off);
     }
+    EVENT(RTO_E_SURFACE, (float)*cnt, 0.0f, 0.0f);
+    EVENT(RTO_E_DIR, D.x, D.y, D.z);
+#ifndef RTO_NO_DECISIONS
+    if (g_inj.rows && g_inj.next < g_inj.n) {
+        const float* r = g_inj.rows + 10 * (size_t)g_inj.next++;
+        ray->direction = v3_make(r[0], r[1], r[2]);
+        ray->color = v3_make(r[3], r[4], r[5]);
+        ray->origin = v3_make(r[6], r[7], r[8]);
+        *cnt = (uint32_t)r[9];
+    }
+#endif
 }
 
 /* ------------------------------------------------------------------ sky
@@ -326,7 +404,7 @@ static v3 sky_color(struct rto_ctx* c, v3 D, rtpbr_counters* ctr) {
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && c->env) {
         float u = rto_atan2f(D.z, D.x) * RTO_INV_2PI + 0.5f;
         float v = rto_asinf(D.y) * RTO_INV_PI + 0.5f;
-        int x = (int)(u * (float)c->env_w), y = (int)(v * (float)c->env_h);
+        int x = DEC_FLOOR(RTO_D_ENV_X, u * (float)c->env_w, (float)c->env_w), y = DEC_FLOOR(RTO_D_ENV_Y, v * (float)c->env_h, (float)c->env_h);
         if (x < 0) x = 0; if (x > c->env_w - 1) x = c->env_w - 1;   /* G6: clamped */
         if (y < 0) y = 0; if (y > c->env_h - 1) y = c->env_h - 1;
         const float* t = c->env + ((size_t)x * c->env_h + y) * 3;
@@ -396,7 +474,7 @@ static v3 sample_complete_n(struct rto_ctx* c, const cam_frame* f, int px, int p
     for (int i = 0; i < g->max_raytrace; i++) {
         float inv_pdf = rto_expf((float)i / g->light_quality);
         float p = 1.0f - 1.0f / inv_pdf;
-        if (rto_rand(key, &cnt) < p) { ray.color = v3_scale(ray.color, p); break; }
+        if (DEC(RTO_D_ROULETTE, rto_rand(key, &cnt), p, 1.0f)) { ray.color = v3_scale(ray.color, p); break; }
         v3 pos; int hit, idx;
         if (g->march_kind == RTPBR_MARCH_PLAIN) idx = raycast_plain(c, &ray, &pos, &hit, ctr);
         else idx = raycast_relaxed(c, &ray, &pos, &hit, ctr);
@@ -413,7 +491,8 @@ static v3 sample_complete_n(struct rto_ctx* c, const cam_frame* f, int px, int p
         float intensity = brightness(ray.color);
         ray.color = v3_mul(ray.color, v3_make(o->material.emission[0], o->material.emission[1], o->material.emission[2]));
         float visible = brightness(ray.color);
-        if (intensity < visible || visible < g->vis_lo || visible > g->vis_hi) break;
+        if (DEC(RTO_D_STOP_GAIN, intensity, visible, fmaxf(intensity, visible)) || DEC(RTO_D_STOP_LO, visible, g->vis_lo, g->vis_lo)
+            || DEC(RTO_D_STOP_HI, g->vis_hi, visible, g->vis_hi)) break;
     }
     ctr->samples++;
     if (draws) *draws = cnt;
@@ -438,7 +517,7 @@ static void step_persistent(struct rto_ctx* c, const cam_frame* f, int px, int p
     /* russian_roulette :65-77 */
     float p = (ray.depth == 0) ? 1.0f : g->quality_per_sample;
     p -= (float)ray.depth * (1.0f / (float)g->max_raytrace);
-    if (rto_rand(key, &cnt) > p) {
+    if (DEC(RTO_D_ROULETTE, p, rto_rand(key, &cnt), 1.0f)) {
         ray.color = v3_make(0, 0, 0);
         ray.depth = -ray.depth;
     } else {
@@ -460,7 +539,8 @@ static void step_persistent(struct rto_ctx* c, const cam_frame* f, int px, int p
             float intensity = brightness(ray.color);
             ray.color = v3_mul(ray.color, v3_make(o->material.emission[0], o->material.emission[1], o->material.emission[2]));
             float visible = brightness(ray.color);
-            int stop = intensity < visible || visible < g->vis_lo || visible > g->vis_hi;
+            int stop = DEC(RTO_D_STOP_GAIN, intensity, visible, fmaxf(intensity, visible)) || DEC(RTO_D_STOP_LO, visible, g->vis_lo, g->vis_lo)
+                       || DEC(RTO_D_STOP_HI, g->vis_hi, visible, g->vis_hi);
             if (stop) ray.depth = -ray.depth;
         } else {
             ray.depth = -ray.depth;
@@ -519,7 +599,7 @@ static v3 tone_map(const rtpbr_config* g, const float* b) {
  * Sums are evaluated as fma chains (order: see below) and the activations with rto_sin_pi (exactly specified). */
 static float sd_bunny(v3 p) {
     float len = v3_length(p);
-    if (len > 1.0f) return len - 0.8f;
+    if (DEC(RTO_D_BOUND, 1.0f, len, 1.0f)) return len - 0.8f;
     if (!g_bunny_set) return len - 0.8f;
     t_mlp_evals++;
     const float* w = g_bunny;
@@ -610,6 +690,11 @@ int rto_set_scene(struct rto_ctx* c, const rtpbr_object* objs, int n, int scale1
         rto_rotate(rad, t->matrix);
     }
     c->n_obj = n;
+    c->extent = 1.0f;
+    for (int i = 0; i < n; i++) {
+        const rtpbr_transform* t = &c->obj[i].transform;
+        for (int k = 0; k < 3; k++) c->extent = fmaxf(c->extent, fabsf(t->position[k]) + fabsf(t->scale[k]));
+    }
     c->have_scene = 1;
     return RTPBR_OK;
 }
@@ -864,6 +949,62 @@ int rto_test_sample(struct rto_ctx* c, int px, int py, uint32_t sidx, float* col
     v3 col = sample_complete_n(c, &f, px, py, sidx, &k, &draws);
     color3[0] = col.x; color3[1] = col.y; color3[2] = col.z;
     stats3[0] = (uint32_t)k.raycasts; stats3[1] = (uint32_t)k.march_steps; stats3[2] = draws;
+    return RTPBR_OK;
+}
+/* Decision session for ANY of the rto_test_* hooks called next on this thread (ctypes calls stay on the caller's thread):
+ * begin() arms the log / the flips / the surface-output injection, end() disarms and returns the number of log entries. */
+int rto_test_decisions_begin(const int* flips, int n_flips, rto_decision* log, int cap, const float* inject_rows, int n_inject) {
+#ifdef RTO_NO_DECISIONS
+    (void)flips; (void)n_flips; (void)log; (void)cap; (void)inject_rows; (void)n_inject;
+    return fail(RTPBR_ESTATE, "built without the decision log");
+#else
+    g_dec.active = 1; g_dec.n = 0; g_dec.cap = cap; g_dec.log = log; g_dec.flip = flips; g_dec.n_flip = n_flips;
+    g_inj.rows = inject_rows; g_inj.n = n_inject; g_inj.next = 0;
+    return RTPBR_OK;
+#endif
+}
+int rto_test_decisions_end(void) {
+#ifdef RTO_NO_DECISIONS
+    return 0;
+#else
+    const int n = g_dec.n;
+    g_dec.active = 0; g_dec.log = NULL; g_dec.n_flip = 0; g_dec.flip = NULL;
+    g_inj.rows = NULL; g_inj.n = g_inj.next = 0;
+    return n;
+#endif
+}
+/* The same sample with the decision log on: decisions whose ordinals are listed in flips[] are taken the other way.
+ * log (may be NULL) receives up to cap entries; *n_log = number of decisions and events the sample went through. */
+int rto_test_sample_decisions(struct rto_ctx* c, int px, int py, uint32_t sidx, const int* flips, int n_flips,
+                              rto_decision* log, int cap, int* n_log, float* color3, uint32_t* stats3) {
+#ifdef RTO_NO_DECISIONS
+    (void)c; (void)px; (void)py; (void)sidx; (void)flips; (void)n_flips; (void)log; (void)cap; (void)n_log; (void)color3; (void)stats3;
+    return fail(RTPBR_ESTATE, "built without the decision log");
+#else
+    g_dec.active = 1; g_dec.n = 0; g_dec.cap = cap; g_dec.log = log; g_dec.flip = flips; g_dec.n_flip = n_flips;
+    int r = rto_test_sample(c, px, py, sidx, color3, stats3);
+    if (n_log) *n_log = g_dec.n;
+    g_dec.active = 0; g_dec.log = NULL; g_dec.n_flip = 0;
+    return r;
+#endif
+}
+/* One bounce-step of the persistent-ray form for one pixel from a given ray state (10 words: origin, direction, colour,
+ * depth bits): returns the new state and what the step deposited (4 floats, zero if nothing).  The context's own buffers
+ * are left as they were.  (Runs inside a decision session like every other hook.) */
+int rto_test_step(struct rto_ctx* c, int px, int py, uint32_t step, const float* ray_in10, float* ray_out10, float* deposit4) {
+    if (!c || !c->ray_buffer || px < 0 || py < 0 || px >= c->cfg.width || py >= c->cfg.height) return fail(RTPBR_EINVAL, "bad pixel");
+    cam_frame f; camera_frame(c, &f);
+    rtpbr_counters k; memset(&k, 0, sizeof k);
+    const size_t pi = (size_t)px * c->cfg.height + py;
+    rtpbr_ray saved = c->ray_buffer[pi];
+    float ib[4]; memcpy(ib, c->image_buffer + pi * 4, sizeof ib);
+    memcpy(&c->ray_buffer[pi], ray_in10, sizeof(rtpbr_ray));
+    memset(c->image_buffer + pi * 4, 0, sizeof ib);
+    step_persistent(c, &f, px, py, step, &k);
+    memcpy(ray_out10, &c->ray_buffer[pi], sizeof(rtpbr_ray));
+    memcpy(deposit4, c->image_buffer + pi * 4, sizeof ib);
+    c->ray_buffer[pi] = saved;
+    memcpy(c->image_buffer + pi * 4, ib, sizeof ib);
     return RTPBR_OK;
 }
 /* surface interaction with explicit incoming colour and RNG position (stream (px,py,sidx), draw n0).

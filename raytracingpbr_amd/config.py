@@ -62,6 +62,7 @@ class Config(C.Structure):
         ("exposure", C.c_float), ("gamma", C.c_float),
         ("frame", C.c_int32), ("steps_per_launch", C.c_int32),
         ("adaptive_sampling", C.c_int32), ("noise_threshold", C.c_float),
+        ("anim_bob", C.c_float),
     ]
 
     def copy(self, **kw):
@@ -97,6 +98,7 @@ class Config(C.Structure):
         c.tonemap_order, c.aces_truncated, c.exposure, c.gamma = TONEMAP.GAMMA_ACES_CLAMP, 0, 1.0, 2.2
         c.frame, c.steps_per_launch = 0, 1
         c.adaptive_sampling, c.noise_threshold = 0, 1e-4          # src/config.py:14,17
+        c.anim_bob = 0.0
         return c
 
     @staticmethod
@@ -165,6 +167,7 @@ class Config(C.Structure):
         c.sky_kind = SKY.ENVMAP
         c.tonemap_order, c.exposure = TONEMAP.ACES_CLAMP_GAMMA, 0.8
         c.frame = frame
+        c.anim_bob = 0.1                                          # bunny_sdf_glass.py:216  p += vec3(0, 0, 0.1*sin(t))
         return c
 
     @staticmethod
@@ -175,6 +178,7 @@ class Config(C.Structure):
         c.omega0, c.omega_fb_a = 1.6, 0.7
         c.primary_miss = PRIMARY.WHITE if v2 else PRIMARY.BLACK
         c.exposure = 0.8 if v2 else 0.6
+        c.anim_bob = 0.1 if v2 else 0.0                          # bunny_sdf_v2.py:216 bobs; bunny_sdf.py:213-214 only rotates
         return c
 
     @staticmethod

@@ -165,6 +165,7 @@ extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
     // bunny animation uniform: t = pi*frame/120 (bunny_sdf_glass.py:214)
     float t = PI * (float)cfg->frame / 120.0f;
     sincos_(t, &c->P.anim_s, &c->P.anim_c);
+    c->P.anim_bz = cfg->anim_bob * c->P.anim_s;
     update_tiles(c);
     return RTPBR_OK;
 }

@@ -309,7 +309,7 @@ RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL)
     if (KIND == KIND_BUNNY || (KIND == KIND_MIXED && o.type == RTPBR_SHAPE_BUNNY)) {
         float st = P.anim_s, ct = P.anim_c;
         vec3 r = mk(fma_(st, l.y, ct * l.x), fma_(ct, l.y, -st * l.x), l.z);
-        r.z = r.z + 0.1f * st;
+        r.z = r.z + P.anim_bz;
         l = r;
     }
     return l;

@@ -18,7 +18,7 @@
 namespace rt {
 
 constexpr int MAX_OBJ = RTPBR_MAX_OBJECTS;
-static_assert(sizeof(rtpbr_config) == 160 && sizeof(rtpbr_object) == 116 && sizeof(rtpbr_camera) == 52 &&
+static_assert(sizeof(rtpbr_config) == 164 && sizeof(rtpbr_object) == 116 && sizeof(rtpbr_camera) == 52 &&
                   sizeof(rtpbr_ray) == 40,
               "C-ABI struct layout changed");
 
@@ -112,6 +112,7 @@ struct Params {
     int32_t n_obj;
     // bunny animation (bunny_sdf_glass.py:213-217): sin/cos of t = pi*frame/120, host-computed
     float anim_s, anim_c;
+    float anim_bz;          // cfg.anim_bob * anim_s: the frame's vertical bob (bunny_sdf_glass.py:216), host-computed
     // work geometry
     uint32_t sample_base;   // absolute index of the first sample (or bounce-step) of this launch
     int32_t K;              // samples per pixel in this sub-launch

@@ -26,11 +26,38 @@ def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
-def both(scene, cfg, setup):
-    g, o = Renderer(scene, cfg), OracleRenderer(scene, cfg)
+VARIANTS = ["aot", "jit_baked"]      # the ahead-of-time kernels, and what bench.py times: run-time compiled for the scene, baked
+
+
+def hip(scene, cfg, setup, variant):
+    g = Renderer(scene, cfg)
     setup(g)
+    if variant == "jit_baked":
+        g.set_option("jit", 2)            # strict: an error if the run-time instance cannot be used
+        g.set_option("jit_bake", 1)
+    return g
+
+
+_ORACLE = {}
+
+
+def oracle_once(key, make):
+    """oracle results shared by the kernel variants of one test: (image_buffer, counters)"""
+    if key not in _ORACLE:
+        o = make()
+        _ORACLE[key] = (o.image_buffer, counters(o))
+    return _ORACLE[key]
+
+
+def both(scene, cfg, setup, variant="aot"):
+    g, o = hip(scene, cfg, setup, variant), OracleRenderer(scene, cfg)
     setup(o)
     return g, o
+
+
+@pytest.fixture(autouse=True)
+def _private_jit_cache(tmp_path, monkeypatch):
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
 
 
 def counters(r):
@@ -39,7 +66,8 @@ def counters(r):
 
 
 # ---------------------------------------------------------------------------------------------- C3
-def test_c3_glass_bunny_1080p_1024spp():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_c3_glass_bunny_1080p_1024spp(variant):
     W, H, SPP = 1920, 1080, 1024
     sc = bunny(aspect=W / H)
     cfg = Config.bunny_glass(W, H, seed=0, max_raytrace=16, frame=0)
@@ -49,22 +77,29 @@ def test_c3_glass_bunny_1080p_1024spp():
     def setup(r):
         r.set_env(env, 1.8, 2.2)
         r.set_shape_data(SHAPE.BUNNY, load_bunny_weights())
+    def o_full():
+        o = OracleRenderer(sc, cfg); setup(o); o.sample(1)
+        return o
+
+    def o_sub():
+        o = OracleRenderer(sc, cfg); setup(o); o.set_tiles(16, 16, 437, 1020); o.sample(SPP)
+        return o
     # (a) full frame, first sample of every pixel
-    g, o = both(sc, cfg, setup)
+    g = hip(sc, cfg, setup, variant)
     g.sample(1)
-    o.sample(1)
-    assert counters(g) == counters(o)
-    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+    assert g.counter("jit_active") == (1 if variant == "jit_baked" else 0)
+    want, want_ctr = oracle_once("c3_full", o_full)
+    assert counters(g) == want_ctr
+    assert np.array_equal(bits(g.image_buffer), bits(want))
     # (b) 8 tiles of 16x16 (one of 1020 ranks), all 1024 samples
     world = 1020
-    gs, os_ = both(sc, cfg, setup)
+    gs = hip(sc, cfg, setup, variant)
     gs.set_tiles(16, 16, 437, world)
-    os_.set_tiles(16, 16, 437, world)
     gs.sample(SPP)
-    os_.sample(SPP)
     sub = gs.image_buffer
-    assert counters(gs) == counters(os_)
-    assert np.array_equal(bits(sub), bits(os_.image_buffer))
+    want, want_ctr = oracle_once("c3_sub", o_sub)
+    assert counters(gs) == want_ctr
+    assert np.array_equal(bits(sub), bits(want))
     own = TileLayout(W, H, 16, 16, world).owner_map() == 437
     assert own.sum() == 8 * 256 and np.all(sub[own][:, 3] == SPP)
     # (c) the full config: 2.1 G samples
@@ -80,7 +115,8 @@ def test_c3_glass_bunny_1080p_1024spp():
 
 
 # ---------------------------------------------------------------------------------------------- C4
-def test_c4_tokyo_ibl_4k_four_ranks():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_c4_tokyo_ibl_4k_four_ranks(variant):
     W, H, SPP, G = 3840, 2160, 512, 4
     sc = src_scene(aspect=W / H, tokyo=True)
     cfg = Config.tokyo_ibl(W, H, seed=0, max_raytrace=512)
@@ -90,30 +126,31 @@ def test_c4_tokyo_ibl_4k_four_ranks():
         r.set_env(env, 1.8, 2.2)
     # (b) sparse subset at full spp vs the oracle (exercises the 57 MB env gather on the device)
     world = 4050
-    gs, os_ = both(sc, cfg, setup)
+
+    def o_sub():
+        o = OracleRenderer(sc, cfg); setup(o); o.set_tiles(16, 16, 1234, world); o.sample(SPP)
+        return o
+    gs = hip(sc, cfg, setup, variant)
     gs.set_tiles(16, 16, 1234, world)
-    os_.set_tiles(16, 16, 1234, world)
     gs.sample(SPP)
-    os_.sample(SPP)
+    assert gs.counter("jit_active") == (1 if variant == "jit_baked" else 0)
     sub = gs.image_buffer
-    assert counters(gs) == counters(os_)
-    assert np.array_equal(bits(sub), bits(os_.image_buffer))
+    want, want_ctr = oracle_once("c4_sub", o_sub)
+    assert counters(gs) == want_ctr
+    assert np.array_equal(bits(sub), bits(want))
     own_sub = TileLayout(W, H, 16, 16, world).owner_map() == 1234
     # (c) gathered frame == untiled frame at 2 spp: G virtual ranks render, pack, rank 0 unpacks
     import torch
     lay = TileLayout(W, H, 32, 32, G)
-    ref = Renderer(sc, cfg)
-    setup(ref)
+    ref = hip(sc, cfg, setup, variant)
     ref.sample(2)
     want = ref.image_buffer
     ref.close()
-    root = Renderer(sc, cfg)
-    setup(root)
+    root = hip(sc, cfg, setup, variant)
     root.set_tiles(32, 32, 0, G)
     root.sample(2)
     for rank in range(1, G):
-        r = Renderer(sc, cfg)
-        setup(r)
+        r = hip(sc, cfg, setup, variant)
         r.set_tiles(32, 32, rank, G)
         r.sample(2)
         buf = torch.empty(lay.packed_pixels * 4, dtype=torch.float32, device="cuda")
@@ -136,36 +173,42 @@ def test_c4_tokyo_ibl_4k_four_ranks():
 
 
 # ---------------------------------------------------------------------------------------------- C5
-def test_c5_cornell_8k_eight_ranks_progressive():
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_c5_cornell_8k_eight_ranks_progressive(variant):
     W, H, G = 7680, 4320, 8
     sc = cornell_box("v3", aspect=W / H)
     cfg = Config.cornell_v3(W, H, seed=0, max_raytrace=8)
     lay = TileLayout(W, H, 32, 32, G)
     mine = lay.owner_map() == 0
     # rank 0 of 8: two progressive calls of 256 spp (the config accumulates 16 of them)
-    g = Renderer(sc, cfg)
+    nothing = lambda r: None
+    g = hip(sc, cfg, nothing, variant)
     g.set_tiles(32, 32, 0, G)
     g.sample(256)
     g.sample(256)
+    assert g.counter("jit_active") == (1 if variant == "jit_baked" else 0)
     two = g.image_buffer
     assert np.all(two[mine][:, 3] == 512) and np.all(two[~mine] == 0) and np.all(np.isfinite(two))
     assert g.packed_bytes() == lay.packed_pixels * 16
     # additivity: 512 straight == 256 + 256 (sample indices continue)
-    s = Renderer(sc, cfg)
+    s = hip(sc, cfg, nothing, variant)
     s.set_tiles(32, 32, 0, G)
     s.sample(512)
     assert np.array_equal(bits(s.image_buffer), bits(two))
     s.close()
     # (b) sparse subset (one of 16200 ranks of 16x16 tiles = 8 tiles) at 512 spp vs the oracle
     world = 16200
-    gs, os_ = both(sc, cfg, lambda r: None)
+
+    def o_sub():
+        o = OracleRenderer(sc, cfg); o.set_tiles(16, 16, 7777, world); o.sample(512)
+        return o
+    gs = hip(sc, cfg, nothing, variant)
     gs.set_tiles(16, 16, 7777, world)
-    os_.set_tiles(16, 16, 7777, world)
     gs.sample(512)
-    os_.sample(512)
     sub = gs.image_buffer
-    assert counters(gs) == counters(os_)
-    assert np.array_equal(bits(sub), bits(os_.image_buffer))
+    want, want_ctr = oracle_once("c5_sub", o_sub)
+    assert counters(gs) == want_ctr
+    assert np.array_equal(bits(sub), bits(want))
     own_sub = TileLayout(W, H, 16, 16, world).owner_map() == 7777
     both_ = mine & own_sub
     assert both_.any() and np.array_equal(bits(two[both_]), bits(sub[both_]))

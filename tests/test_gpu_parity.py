@@ -377,25 +377,50 @@ def test_error_channel():
     assert np.array_equal(bits(g.image_buffer), want)
 
 
-def test_full_size_cornell_1080p():
-    """BASELINE.json configs[1] geometry: Cornell 1920x1080, 8 bounces.  The oracle cannot do
-    256 spp on the full frame in seconds, so: (a) the whole frame at 1 spp is bit-exact;
-    (b) a sparse 1/128 tile subset at 256 spp is bit-exact; (c) size-independent properties:
+_ORACLE_C2 = {}
+
+
+def _oracle_c2(sc, cfg):
+    """the oracle's share of the 1080p checks, computed once for both kernel variants"""
+    if not _ORACLE_C2:
+        o = OracleRenderer(sc, cfg); o.sample(1)
+        os_ = OracleRenderer(sc, cfg); os_.set_tiles(16, 16, 5, 128); os_.sample(256)
+        _ORACLE_C2.update(one=o.image_buffer, one_ctr=o.counters(), sub=os_.image_buffer, sub_ctr=os_.counters())
+    return _ORACLE_C2
+
+
+def _ctr(c):
+    return (c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits)
+
+
+@pytest.mark.parametrize("variant", ["aot", "jit_baked"])
+def test_full_size_cornell_1080p(variant, tmp_path, monkeypatch):
+    """BASELINE.json configs[1] geometry: Cornell 1920x1080, 8 bounces, through the ahead-of-time kernels AND through the
+    kernels bench.py times (run-time compiled for the scene, object table and configuration baked: jit + jit_bake).  The
+    oracle cannot do 256 spp on the full frame in seconds, so: (a) the whole frame at 1 spp is bit-exact, work counters
+    included; (b) a sparse 1/128 tile subset at 256 spp is bit-exact, counters included; (c) size-independent properties:
     count == spp everywhere, tile-partition invariance, spp additivity."""
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
     W, H = 1920, 1080
     sc = cornell_box("v3", aspect=W / H)
     cfg = Config.cornell_v3(W, H, seed=0, max_raytrace=8)
-    g = Renderer(sc, cfg)
+
+    def make():
+        r = Renderer(sc, cfg)
+        if variant == "jit_baked":
+            r.set_option("jit", 2)                       # strict: an error if the run-time instance cannot be used
+            r.set_option("jit_bake", 1)
+        return r
+    want = _oracle_c2(sc, cfg)
+    g = make()
     g.sample(1)
-    o = OracleRenderer(sc, cfg)
-    o.sample(1)
+    assert g.counter("jit_active") == (1 if variant == "jit_baked" else 0)
     one = g.image_buffer
-    assert np.array_equal(bits(one), bits(o.image_buffer))
+    assert np.array_equal(bits(one), bits(want["one"])) and _ctr(g.counters()) == _ctr(want["one_ctr"])
     # (b) sparse subset, 256 spp
-    gs = Renderer(sc, cfg); gs.set_tiles(16, 16, 5, 128); gs.sample(256)
-    os_ = OracleRenderer(sc, cfg); os_.set_tiles(16, 16, 5, 128); os_.sample(256)
+    gs = make(); gs.set_tiles(16, 16, 5, 128); gs.sample(256)
     sub = gs.image_buffer
-    assert np.array_equal(bits(sub), bits(os_.image_buffer))
+    assert np.array_equal(bits(sub), bits(want["sub"])) and _ctr(gs.counters()) == _ctr(want["sub_ctr"])
     own = TileLayout(W, H, 16, 16, 128).owner_map() == 5
     assert np.all(sub[own][:, 3] == 256.0) and np.all(sub[~own] == 0)
     # (c) full frame 256 spp: counts, additivity (1 + 255 == 256 straight), subset consistency

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(Config) == 160
+    assert C.sizeof(Config) == 164
     assert C.sizeof(rt.Ray) == 40 and C.sizeof(rt.Material) == 40 and C.sizeof(rt.Transform) == 72
     assert C.sizeof(rt.SDFObject) == 116 and C.sizeof(rt.Camera) == 52
     # field order of Config == field order of rtpbr_config in include/rtpbr.h

@@ -12,6 +12,21 @@ rounding.  Tolerances exist because the two sides round differently where Taichi
 open (the oracle fuses dot products and uses fixed polynomial sin/cos/exp; the stand-in evaluates
 left-to-right IEEE f32 with NumPy's libm) — see DESIGN.md section 2.  A misreading of the reference
 (wrong branch, wrong constant, wrong draw order, wrong operand) shows up as O(1) differences.
+
+No acceptance fractions.  Three layers, each complete (every recorded row is checked):
+  (1) every raycast the reference made, re-run by the oracle from the reference's own (origin, direction): same hit flag and
+      march-step count, hit position to rounding;
+  (2) every surface interaction, re-run from the reference's own inputs (position, incoming direction and colour, RNG
+      position): same RNG draw count, same normal / outgoing direction / colour / origin to rounding;
+  (3) every sample: identical counts and colour to rounding — or, for the few samples whose own path drifts (a rounding
+      difference amplified by a rounded box edge of radius 0.01, by the 100-unit ground sphere's finite-difference normal, or
+      by the neural bunny's h = 1e-4 normals), the run with the reference's recorded interaction outputs INJECTED
+      (rto_test_decisions_begin: the oracle then stays on the reference's trajectory and executes everything else itself:
+      roulette, stop tests, raycasts, environment lookup) must reproduce the reference's counts and colour.
+A row that fails (1), (2) or the injected (3) must be CLASSIFIED or the test fails: the oracle logs every data-dependent
+decision with both operands and the magnitude `scale` of what went into them (oracle/rt_oracle.c, DEC); there must be a
+decision in the differing stretch whose operands agree to <= N ulp(scale), and taking it the other way must reproduce
+the reference's row.  N is stated per script (NEAR_TIE_ULPS) next to the reason for its size.
 """
 import ast
 import ctypes as C
@@ -64,6 +79,14 @@ def lib():
     l.rto_test_bunny.argtypes = [F3]
     l.rto_get_scene.argtypes = [C.c_void_p, C.POINTER(SDFObject), C.c_int]
     l.rto_rotate.argtypes = [F3, C.c_float * 9]
+    l.rto_test_sample_decisions.restype = C.c_int
+    l.rto_test_sample_decisions.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_int), C.c_int, C.POINTER(Decision), C.c_int,
+                                            C.POINTER(C.c_int), F3, C.c_uint32 * 3]
+    l.rto_test_decisions_begin.restype = C.c_int
+    l.rto_test_decisions_begin.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(Decision), C.c_int, C.POINTER(C.c_float), C.c_int]
+    l.rto_test_decisions_end.restype = C.c_int
+    l.rto_test_step.restype = C.c_int
+    l.rto_test_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     return l
 
 
@@ -115,32 +138,240 @@ def setup_variant(meta, env_u8=None):
     return o
 
 
-# fraction of samples that must agree, and colour tolerance, per script.  Cornell variants: colours are products of
-# table constants, so they agree to rounding unless a branch flips.  Sky-lit scenes: the colour depends continuously on
-# the final direction, and the 100-unit ground sphere's finite-difference normal (h = 0.0029 on |p - c| ~ 100)
-# amplifies f32 rounding to ~3e-3.  Neural bunny: normal_h = 1e-4 on an f32 MLP gives normals that are noisy at the
-# 1e-2 level in the reference itself, so paths that graze the silhouette split; sd_bunny and raycast are pinned at
-# function level instead (test_bunny_sdf_and_raycast).
-MATCH = {"v2": (0.995, 2e-5), "v1": (0.99, 2e-5), "shortest": (0.995, 2e-5), "scene_demo": (0.99, 1e-2), "tokyo": (0.98, 1e-2),
-         "bunny_glass": (0.95, 1e-2), "bunny_sdf": (0.85, 1e-2), "bunny_sdf_v2": (0.85, 1e-2)}
+# Colour tolerance per script.  Cornell variants: colours are products of table constants, so they agree to rounding
+# unless a branch flips.  Sky-lit scenes: the colour depends continuously on the final direction, and the 100-unit ground
+# sphere's finite-difference normal (h = 0.0029 on |p - c| ~ 100) amplifies f32 rounding to ~3e-3.  Neural bunny:
+# normal_h = 1e-4 on an f32 MLP gives normals that are noisy at the 1e-2 level in the reference itself (sd_bunny and
+# raycast are pinned at function level, test_bunny_sdf_and_raycast).
+RTOL = {"src": 1e-2, "v3": 2e-5, "v3b8": 2e-5, "v2": 2e-5, "v1": 2e-5, "shortest": 2e-5, "scene_demo": 1e-2, "tokyo": 1e-2,
+        "bunny_glass": 1e-2, "bunny_sdf": 1e-2, "bunny_sdf_v2": 1e-2}
+# direction tolerance of a surface interaction's outgoing ray when lining the oracle's events up with the reference's
+DIR_TOL = {"v3": 3e-4, "v3b8": 3e-4, "v2": 3e-4, "v1": 3e-4, "shortest": 3e-4, "scene_demo": 2e-2, "tokyo": 2e-2,
+           "bunny_glass": 6e-2, "bunny_sdf": 6e-2, "bunny_sdf_v2": 6e-2}
+# N: a decision may only be called a rounding flip when its operands agree to this many ulps of `scale` (the magnitude
+# of the largest intermediate behind them, logged by the oracle).  Because layers (1) and (2) start from the reference's
+# own inputs and layer (3) follows the reference's trajectory, only ONE function's rounding separates the two sides at
+# any decision — every flip found in the fixtures has a margin below 1 ulp — so N is the same small number for every
+# script: 4 ulps.
+NEAR_TIE_ULPS = {t: 4 for t in ("src", "v3", "v3b8", "v2", "v1", "shortest", "scene_demo", "tokyo", "bunny_glass", "bunny_sdf", "bunny_sdf_v2")}
+
+D_NAMES = {1: "nearest", 2: "hit", 3: "fallback", 4: "escape", 5: "outer", 6: "reflect", 7: "tir", 8: "transmit", 9: "horizon",
+           10: "stop_gain", 11: "stop_lo", 12: "stop_hi", 13: "roulette", 14: "env_x", 15: "env_y", 16: "bound"}
+E_RAYCAST, E_SURFACE, E_DIR = 100, 101, 102
 
 
-def check_samples(l, o, d, min_match, rtol=2e-5):
-    """every recorded sample of the reference's raytrace(): colour + draw count (+ raycasts/steps when recorded)"""
-    n = len(d["samples__px"])
+class Decision(C.Structure):
+    _fields_ = [("kind", C.c_int), ("outcome", C.c_int), ("a", C.c_float), ("b", C.c_float), ("scale", C.c_float)]
+
+
+LOG_CAP = 1 << 16
+
+
+class Session:
+    """decision session around any oracle test hook: log, flips, injected surface outputs"""
+
+    def __init__(self, l, flips=(), inject=None):
+        self.l, self.flips = l, list(flips)
+        self.log = (Decision * LOG_CAP)()
+        self.fl = (C.c_int * max(len(self.flips), 1))(*self.flips)
+        self.inj = None if inject is None else np.ascontiguousarray(inject, np.float32)
+        self.n = 0
+
+    def __enter__(self):
+        ip = None if self.inj is None else self.inj.ctypes.data_as(C.POINTER(C.c_float))
+        assert self.l.rto_test_decisions_begin(self.fl, len(self.flips), self.log, LOG_CAP, ip, 0 if self.inj is None else len(self.inj)) == 0
+        return self
+
+    def __exit__(self, *exc):
+        self.n = self.l.rto_test_decisions_end()
+        assert self.n <= LOG_CAP
+        return False
+
+    def decisions(self):
+        return [(i, self.log[i]) for i in range(self.n) if flippable(self.log[i])]
+
+
+def margin_ulps(d):
+    sc = min(max(abs(float(d.scale)), 1e-30), 1e30)
+    return abs(float(d.a) - float(d.b)) / float(np.spacing(np.float32(sc)))
+
+
+def flippable(d):
+    """a decision that rounding can take either way: not an event entry, not a test against an 'infinite' bound (vis_hi =
+    FLT_MAX), not the structural tie intensity == visible of a surface whose emission multiplier is exactly 1"""
+    return d.kind < 100 and abs(float(d.scale)) < 1e30 and not (d.kind == 10 and d.a == d.b)
+
+
+def classify(l, tag, what, run, agrees, inject=None, max_flips=3):
+    """`run()` executes one oracle hook and returns its outputs, `agrees(outputs)` compares them with the reference's row.
+    Called when the plain run disagrees: finds decisions (margin <= N ulps, nearest ties first) that make the run agree when
+    taken the other way.  Returns [(decision, ulps)]; raises when there are none."""
+    N = NEAR_TIE_ULPS[tag]
+    flips, why = [], []
+    for _ in range(max_flips):
+        with Session(l, flips, inject) as s0:
+            run()
+        cands = sorted((margin_ulps(d), i, d.kind) for i, d in s0.decisions() if i not in flips)
+        for m, i, kind in [c for c in cands if c[0] <= N]:
+            with Session(l, flips + [i], inject):
+                out = run()
+            if agrees(out):
+                return why + [(D_NAMES.get(kind, str(kind)), round(m, 1))]
+        # no single decision does it: a second near-tie may sit behind the first (take the nearest tie and look again)
+        if not cands or cands[0][0] > N:
+            break
+        flips.append(cands[0][1])
+        why.append((D_NAMES.get(cands[0][2], str(cands[0][2])), round(cands[0][0], 1)))
+    near = [(D_NAMES.get(k), round(m, 1)) for m, i, k in cands[:4]]
+    raise AssertionError(f"{tag} {what}: differs from the reference and no decision within {N} ulps explains it; nearest ties: {near}")
+
+
+class Tally:
+    def __init__(self, tag, what):
+        self.tag, self.what, self.n, self.flips, self.sensitive = tag, what, 0, [], []
+
+    def report(self):
+        worst = max([m for w in self.flips for _, m in w[1]], default=0.0)
+        print(f"[refpin] {self.tag} {self.what}: {self.n - len(self.flips)} of {self.n} identical, {len(self.flips)} near-tie flips "
+              f"(largest margin {worst:.0f} of {NEAR_TIE_ULPS[self.tag]} ulps) {self.flips[:4]}"
+              + (f"; {len(self.sensitive)} rows at ill-conditioned points accepted within 4x their measured 4-ulp spread {self.sensitive[:3]}" if self.sensitive else ""))
+        assert worst <= NEAR_TIE_ULPS[self.tag]
+        return self
+
+
+def scene_extent(o):
+    """max_i(|centre_i| + |size_i|), inf-norm: the magnitude of the intermediates of the SDF evaluation"""
+    return max(max(abs(ob.transform.position[k]) + abs(ob.transform.scale[k]) for k in range(3)) for ob in o.get_scene())
+
+
+def check_raycasts(l, o, d, tag, src_form=False, pos_tol=(2e-6, 2e-5)):
+    """layer (1): every raycast of the reference from its own (origin, direction)"""
+    t = Tally(tag, "raycasts")
+    # absolute position tolerance: 2e-5 for the 13-unit Cornell room = 10 ulps of the scene's magnitude
+    pos_tol = (pos_tol[0], max(pos_tol[1], 10.0 * float(np.spacing(np.float32(scene_extent(o))))))
+    fn = l.rto_test_raycast_src if src_form else l.rto_test_raycast
+    have_obj = "raycasts__obj" in d
+    pos_key = "raycasts__origin_out" if src_form else "raycasts__pos"
+    for k in range(len(d["raycasts__ro"])):
+        t.n += 1
+        ro, rd = F3(*d["raycasts__ro"][k]), F3(*d["raycasts__rd"][k])
+
+        def run():
+            pos, hit, st = F3(), C.c_int(), C.c_int()
+            idx = fn(o._ctx, ro, rd, pos, C.byref(hit), C.byref(st))
+            return idx, bool(hit.value), st.value, a3(pos)
+
+        def agrees(out):
+            idx, hit, st, pos = out
+            # the last evaluated position of an escaping ray is not compared, only hit / step count
+            # (the ray parameter is a running sum: its rounding grows with the number of steps — a ray that slides along a
+            # wall for 90 steps ends 4e-5 away after agreeing on every one of them)
+            return hit == bool(d["raycasts__hit"][k]) and st == d["raycasts__steps"][k] and \
+                (not hit or ((not have_obj or d["raycasts__obj"][k] < 0 or idx == d["raycasts__obj"][k])
+                             and close(pos, d[pos_key][k], pos_tol[0], pos_tol[1] * max(1.0, st / 16.0))))
+        if not agrees(run()):
+            t.flips.append((k, classify(l, tag, f"raycast {k}", run, agrees)))
+    return t.report()
+
+
+def check_surfaces(l, o, d, tag, tol, origin_key="surface__pos", step_key="surface__sample"):
+    """layer (2): every surface interaction of the reference from its own inputs.  tol = (normal, direction) absolute"""
+    t = Tally(tag, "surface interactions")
+    extent = scene_extent(o)
+    for k in range(len(d["surface__obj"])):
+        t.n += 1
+        obj = int(d["surface__obj"][k])
+        assert obj >= 0
+        tn, td = tol(obj) if callable(tol) else tol
+
+        def run():
+            out = (C.c_float * 12)()
+            n1 = l.rto_test_surface_at(o._ctx, obj, F3(*d[origin_key][k]), F3(*d[origin_key][k]), F3(*d["surface__dir_in"][k]),
+                                       F3(*d["surface__color_in"][k]), int(d["surface__px"][k]), int(d["surface__py"][k]),
+                                       int(d[step_key][k]), int(d["surface__n0"][k]), out)
+            return n1, np.array(out[:], np.float32)
+
+        def run_at(pos):
+            out = (C.c_float * 12)()
+            n1 = l.rto_test_surface_at(o._ctx, obj, F3(*pos), F3(*pos), F3(*d["surface__dir_in"][k]),
+                                       F3(*d["surface__color_in"][k]), int(d["surface__px"][k]), int(d["surface__py"][k]),
+                                       int(d[step_key][k]), int(d["surface__n0"][k]), out)
+            return n1, np.array(out[:], np.float32)
+
+        def agrees(res, slack_n=0.0, slack_d=0.0):
+            n1, out = res
+            return n1 == d["surface__n1"][k] and close(out[9:12], d["surface__normal"][k], 1e-5, tn + slack_n) and \
+                close(out[0:3], d["surface__dir_out"][k], 1e-5, td + slack_d) and close(out[3:6], d["surface__color_out"][k], 1e-6, 1e-7) and \
+                close(out[6:9], d["surface__origin_out"][k], 1e-5, 1e-4)
+        res = run()
+        if agrees(res):
+            continue
+        # Ill-conditioned point (a rounded box edge of radius 0.01 under a finite difference of h = 0.003; refraction close to
+        # the critical angle)?  Measure it: move the reference's position by 4 ulps along each axis and see how far the
+        # oracle's own normal and direction move.  A difference within 4x that spread is rounding times the condition
+        # number of the reference's formula at this point, not a disagreement.
+        p0 = np.array(d[origin_key][k], np.float32)
+        step = 4.0 * float(np.spacing(np.float32(max(np.abs(p0).max(), extent))))     # |p - centre| is what gets rounded
+        spread_n = spread_d = 0.0
+        for ax in range(3):
+            for sg in (-1.0, 1.0):
+                q = p0.copy()
+                q[ax] += np.float32(sg * step)
+                n1p, outp = run_at(q)
+                if n1p == res[0]:
+                    spread_n = max(spread_n, float(np.abs(outp[9:12] - res[1][9:12]).max()))
+                    spread_d = max(spread_d, float(np.abs(outp[0:3] - res[1][0:3]).max()))
+        if agrees(res, 4.0 * spread_n, 4.0 * spread_d):
+            t.sensitive.append((k, round(spread_n, 6), round(spread_d, 6)))
+            continue
+        t.flips.append((k, classify(l, tag, f"surface interaction {k}", run, agrees)))
+    return t.report()
+
+
+def injected_rows(d, k):
+    """the reference's recorded outputs of the surface interactions of sample k, in path order (rows of 10 floats)"""
+    px, py, sm = d["samples__px"][k], d["samples__py"][k], d["samples__sample"][k]
+    sf = np.flatnonzero((d["surface__px"] == px) & (d["surface__py"] == py) & (d["surface__sample"] == sm))
+    rows = np.zeros((len(sf), 10), np.float32)
+    rows[:, 0:3], rows[:, 3:6], rows[:, 6:9] = d["surface__dir_out"][sf], d["surface__color_out"][sf], d["surface__origin_out"][sf]
+    rows[:, 9] = d["surface__n1"][sf]
+    return rows
+
+
+def check_samples(l, o, d, tag):
+    """layer (3): every recorded sample of the reference's raytrace().  Returns (samples, {index of a sample that is not
+    identical on the oracle's own path: how it was explained})."""
+    t = Tally(tag, "samples")
     have_counts = "samples__raycasts" in d
-    bad = []
-    for k in range(n):
-        col, st = F3(), (C.c_uint32 * 3)()
-        l.rto_test_sample(o._ctx, int(d["samples__px"][k]), int(d["samples__py"][k]), int(d["samples__sample"][k]), col, st)
-        ok = close(a3(col), d["samples__color"][k], rtol, 1e-7) and st[2] == d["samples__draws"][k]
-        if ok and have_counts:
-            ok = st[0] == d["samples__raycasts"][k] and st[1] == d["samples__steps"][k]
-        if not ok:
-            bad.append((k, a3(col), d["samples__color"][k], list(st), int(d["samples__draws"][k])))
-    frac = 1.0 - len(bad) / n
-    assert frac >= min_match, f"{len(bad)} of {n} samples differ from the reference's own raytrace(): {bad[:5]}"
-    return n, len(bad)
+    have_events = "surface__px" in d
+    drift = {}
+    for k in range(len(d["samples__px"])):
+        t.n += 1
+        px, py, sm = int(d["samples__px"][k]), int(d["samples__py"][k]), int(d["samples__sample"][k])
+
+        def run():
+            col, st = F3(), (C.c_uint32 * 3)()
+            l.rto_test_sample(o._ctx, px, py, sm, col, st)
+            return a3(col), tuple(st)
+
+        def agrees(out):
+            col, st = out
+            return close(col, d["samples__color"][k], RTOL[tag], 1e-7) and st[2] == d["samples__draws"][k] and \
+                (not have_counts or (st[0] == d["samples__raycasts"][k] and st[1] == d["samples__steps"][k]))
+        if agrees(run()):
+            continue
+        assert have_events, f"{tag} sample {k} differs and the fixture holds no events to trace it with"
+        rows = injected_rows(d, k)
+        with Session(l, (), rows):
+            out = run()
+        if agrees(out):
+            drift[k] = "own path drifts; identical on the reference's trajectory"
+        else:
+            drift[k] = classify(l, tag, f"sample {k} (pixel {px},{py} sample {sm}) on the reference's trajectory", run, agrees, inject=rows)
+            t.flips.append((k, drift[k]))
+    t.report()
+    print(f"[refpin] {tag}: samples whose own path drifts from the reference's: {len(drift)} of {t.n}: {sorted(drift.items())[:6]}")
+    return t.n, drift
 
 
 def check_primary_rays(l, o, d, atol=4e-7):
@@ -152,12 +383,17 @@ def check_primary_rays(l, o, d, atol=4e-7):
         assert close(out[3:], d["samples__rd"][k], 1e-6, atol), (k, out, d["samples__rd"][k])
 
 
-def check_frame(o, d, meta, min_match, rtol=2e-5, tone_atol=3e-6):
+def check_frame(o, d, meta, tag, flipped, tone_atol=3e-6):
+    """image_buffer / image_pixels of the reference's own render kernel: every pixel none of whose samples took a
+    classified flip must agree (no acceptance fraction)"""
+    rtol = RTOL[tag]
     o.render(refreshing=True, spp=meta["spp"])
     px = d["frame__pixels"]
     ib = o.image_buffer[px[:, 0], px[:, 1]]
     ok = np.all(np.isclose(ib, d["frame__image_buffer"], rtol=rtol, atol=1e-7), axis=1)
-    assert ok.mean() >= min_match, f"image_buffer: {(~ok).sum()} of {len(ok)} pixels differ"
+    excused = {(int(d["samples__px"][k]), int(d["samples__py"][k])) for k in flipped}
+    bad = [tuple(p) for p in px[~ok] if tuple(int(v) for v in p) not in excused]
+    assert not bad, f"image_buffer differs on pixels with no classified flip: {bad[:5]}"
     assert np.array_equal(ib[:, 3], d["frame__image_buffer"][:, 3])
     ip = o.image_pixels[px[:, 0], px[:, 1]]
     # pow(negative, 1/2.2) = NaN where the ACES fit dips below 0 (ACES -> gamma orders): what clamp() then makes of
@@ -197,41 +433,23 @@ def test_v3_pure_functions():
 
 
 def test_v3_in_situ_functions():
-    """raycast / ray_surface_interaction / calc_normal / get_ray observed while the reference's render kernel ran"""
+    """raycast / ray_surface_interaction / calc_normal / get_ray observed while the reference's render kernel ran: every row"""
     d, meta = load("ref_v3.npz")
     l = lib()
     o = setup_variant(meta)
     check_primary_rays(l, o, d)
-    n, bad = len(d["raycasts__ro"]), 0
-    for k in range(n):
-        pos, hit, st = F3(), C.c_int(), C.c_int()
-        idx = l.rto_test_raycast(o._ctx, F3(*d["raycasts__ro"][k]), F3(*d["raycasts__rd"][k]), pos, C.byref(hit), C.byref(st))
-        # the last evaluated position of an escaping ray (t > 2000) is not compared, only hit / step count
-        ok = bool(hit.value) == bool(d["raycasts__hit"][k]) and st.value == d["raycasts__steps"][k] and \
-            (not hit.value or (idx == d["raycasts__obj"][k] and close(a3(pos), d["raycasts__pos"][k], 2e-6, 2e-5)))
-        bad += not ok
-    assert bad <= 0.002 * n, f"raycast: {bad} of {n} differ"
-    n, bad = len(d["surface__obj"]), 0
-    for k in range(n):
-        out = (C.c_float * 12)()
-        n1 = l.rto_test_surface_at(o._ctx, int(d["surface__obj"][k]), F3(*d["surface__pos"][k]), F3(*d["surface__pos"][k]),
-                                   F3(*d["surface__dir_in"][k]), F3(*d["surface__color_in"][k]), int(d["surface__px"][k]),
-                                   int(d["surface__py"][k]), int(d["surface__sample"][k]), int(d["surface__n0"][k]), out)
-        out = np.array(out[:], np.float32)
-        ok = n1 == d["surface__n1"][k] and close(out[9:12], d["surface__normal"][k], 1e-5, 2e-4) and \
-            close(out[0:3], d["surface__dir_out"][k], 1e-5, 3e-4) and close(out[3:6], d["surface__color_out"][k], 1e-6, 1e-7) and \
-            close(out[6:9], d["surface__origin_out"][k], 1e-6, 1e-6)
-        bad += not ok
-    assert bad <= 0.002 * n, f"ray_surface_interaction: {bad} of {n} differ"
+    rc = check_raycasts(l, o, d, "v3")
+    sf = check_surfaces(l, o, d, "v3", (2e-4, 3e-4))
+    assert rc.n >= 10000 and sf.n >= 9000 and len(rc.flips) <= 0.002 * rc.n and len(sf.flips) <= 0.002 * sf.n
 
 
 def test_v3_samples_and_frame():
     d, meta = load("ref_v3.npz")
     l = lib()
     o = setup_variant(meta)
-    n, bad = check_samples(l, o, d, min_match=0.998)
-    assert n >= 4000
-    check_frame(o, d, meta, min_match=0.995)
+    n, drift = check_samples(l, o, d, "v3")
+    assert n >= 4000 and len(drift) <= 4
+    check_frame(o, d, meta, "v3", drift)
 
 
 def test_v3_eight_bounces():
@@ -240,21 +458,34 @@ def test_v3_eight_bounces():
     assert meta["max_raytrace"] == 8
     l = lib()
     o = setup_variant(meta)
-    check_samples(l, o, d, min_match=0.995)
-    check_frame(o, d, meta, min_match=0.99)
+    check_raycasts(l, o, d, "v3b8")
+    check_surfaces(l, o, d, "v3b8", (2e-4, 3e-4))
+    n, drift = check_samples(l, o, d, "v3b8")
+    assert len(drift) <= 4
+    check_frame(o, d, meta, "v3b8", drift)
     assert d["samples__raycasts"].max() >= 6          # deep paths are present
 
 
 # ---------------------------------------------------------------------------- the other example scripts
+# (normal, direction) tolerance of layer (2): what the script's own finite-difference normal makes of f32 rounding
+SURFACE_TOL = {"v2": (2e-4, 3e-4), "v1": (2e-3, 3e-3), "shortest": (2e-4, 3e-4),
+               "scene_demo": lambda obj: (1e-2, 2e-2) if obj == 0 else (3e-4, 6e-4),      # object 0 = the 100-unit ground sphere
+               "tokyo": lambda obj: (1e-2, 2e-2) if obj == 0 else (3e-4, 6e-4),
+               "bunny_glass": (3e-2, 6e-2), "bunny_sdf": (3e-2, 6e-2), "bunny_sdf_v2": (3e-2, 6e-2)}
+
+
 @pytest.mark.parametrize("tag", ["v2", "v1", "shortest", "scene_demo", "tokyo", "bunny_glass", "bunny_sdf", "bunny_sdf_v2"])
 def test_example_script(tag):
     d, meta = load(f"ref_{tag}.npz")
     l = lib()
     o = setup_variant(meta, d["env__u8"] if "env__u8" in d else None)
-    frac, rtol = MATCH[tag]
     check_primary_rays(l, o, d)
-    check_samples(l, o, d, min_match=frac, rtol=rtol)
-    check_frame(o, d, meta, min_match=frac - 0.03, rtol=rtol)
+    if "raycasts__ro" in d:
+        bunny_scene = tag.startswith("bunny")
+        check_raycasts(l, o, d, tag, pos_tol=(1e-4, 1e-4) if bunny_scene else (2e-6, 2e-5))
+        check_surfaces(l, o, d, tag, SURFACE_TOL[tag])
+    n, drift = check_samples(l, o, d, tag)
+    check_frame(o, d, meta, tag, drift)
 
 
 # ---------------------------------------------------------------------------- neural bunny SDF
@@ -347,35 +578,94 @@ def test_src_in_situ_functions():
         out = np.array(out[:], np.float32)
         assert n1 == 5
         assert close(out[:3], d["gen_ray__ro"][k], 1e-6, 4e-7) and close(out[3:], d["gen_ray__rd"][k], 1e-6, 4e-7)
-    n, bad = len(d["raycasts__ro"]), 0
-    for k in range(n):
-        org, hit, st = F3(), C.c_int(), C.c_int()
-        idx = l.rto_test_raycast_src(o._ctx, F3(*d["raycasts__ro"][k]), F3(*d["raycasts__rd"][k]), org, C.byref(hit), C.byref(st))
-        # an escaping ray's final origin (|p| > 1e3 after steps that grow 2.6x each) is not compared: only the direction
-        # of a miss is used afterwards, and rounding differences grow with the step size
-        ok = bool(hit.value) == bool(d["raycasts__hit"][k]) and st.value == d["raycasts__steps"][k] and \
-            (not hit.value or (idx == d["raycasts__obj"][k] and close(a3(org), d["raycasts__origin_out"][k], 3e-6, 3e-5)))
-        bad += not ok
-    assert bad <= 0.005 * n, f"src raycast: {bad} of {n} differ"
-    n, bad = len(d["surface__obj"]), 0
-    for k in range(n):
-        out = (C.c_float * 12)()
-        n1 = l.rto_test_surface_at(o._ctx, int(d["surface__obj"][k]), F3(*d["surface__origin_in"][k]), F3(*d["surface__origin_in"][k]),
-                                   F3(*d["surface__dir_in"][k]), F3(*d["surface__color_in"][k]), int(d["surface__px"][k]),
-                                   int(d["surface__py"][k]), int(d["surface__step"][k]), int(d["surface__n0"][k]), out)
-        out = np.array(out[:], np.float32)
-        # the ground is a sphere of radius 100: its finite-difference normal (h = 0.0029) amplifies f32 rounding of
-        # |p - c| ~ 100 to ~3e-3 — a property of the reference's algorithm, not of either implementation
-        tol = 1e-2 if d["surface__obj"][k] == 0 else 3e-4
-        ok = n1 == d["surface__n1"][k] and close(out[9:12], d["surface__normal"][k], 0, tol) and \
-            close(out[0:3], d["surface__dir_out"][k], 0, 2 * tol) and close(out[3:6], d["surface__color_out"][k], 1e-6, 1e-7) and \
-            close(out[6:9], d["surface__origin_out"][k], 1e-5, 1e-4)
-        bad += not ok
-    assert bad <= 0.01 * n, f"src ray_surface_interaction: {bad} of {n} differ"
+    # an escaping ray's final origin (|p| > 1e3 after steps that grow 2.6x each) is not compared: only the direction
+    # of a miss is used afterwards, and rounding differences grow with the step size
+    check_raycasts(l, o, d, "src", src_form=True, pos_tol=(3e-6, 3e-5))
+    # the ground is a sphere of radius 100: its finite-difference normal (h = 0.0029) amplifies f32 rounding of
+    # |p - c| ~ 100 to ~3e-3 — a property of the reference's algorithm, not of either implementation
+    check_surfaces(l, o, d, "src", lambda obj: (1e-2, 2e-2) if obj == 0 else (3e-4, 6e-4), origin_key="surface__origin_in", step_key="surface__step")
+
+
+def check_src_steps(l, o, d, meta, tag="src"):
+    """every bounce-step of every recorded pixel, re-run by the oracle FROM THE REFERENCE'S OWN STATE before that step (the
+    ray_buffer of the previous launch, the refreshed state before the first; with several bounce-steps per launch the
+    fixture also holds the state each step started from): same depth incl. sign (every branch of russian_roulette /
+    track_once / raytrace), throughput, ray to rounding, and the launch's deposit — or a classified near-tie flip."""
+    px = d["frame__pixels"]
+    spl = meta.get("steps_per_launch", 1)
+    t = Tally(tag, f"bounce-steps ({spl} per launch)")
+    o.refresh()
+    state0 = o.ray_buffer[px[:, 0], px[:, 1]].copy()               # refresh(): camera state, depth 0 (src/renderer.py:12-22)
+    fp = C.POINTER(C.c_float)
+    inner = {}
+    if spl > 1:
+        inner = {(int(x), int(y), int(s_)): r for x, y, s_, r in zip(d["steps__px"], d["steps__py"], d["steps__step"], d["steps__ray"])}
+
+    def as_state(row, from_fixture):
+        st = np.ascontiguousarray(row, np.float32).copy()
+        if from_fixture:
+            st[9] = np.int32(ref_depth(row)).view(np.float32)      # fixtures hold the depth's VALUE as a float
+        return st
+    for k in range(meta["launches"]):
+        prev_rb = state0 if k == 0 else d["frame__ray_buffer"][k - 1]
+        prev_ib = np.zeros((len(px), 4), np.float32) if k == 0 else d["frame__image_buffer"][k - 1]
+        for j in range(len(px)):
+            ref_end, ref_ib = d["frame__ray_buffer"][k][j], d["frame__image_buffer"][k][j]
+            if ref_ib[3] == prev_ib[j][3] and np.array_equal(ref_end, prev_rb[j]) and "frame__diff_pixels" in d:
+                continue                                           # adaptive sampling: the pixel was masked in this launch
+            x, y = int(px[j, 0]), int(px[j, 1])
+            dep_sum = np.zeros(4, np.float32)
+            for s_ in range(spl):
+                t.n += 1
+                step = k * spl + s_
+                if spl == 1:
+                    sin = as_state(prev_rb[j], k > 0)
+                else:
+                    sin = as_state(inner[(x, y, step)], True)
+                want = ref_end if s_ == spl - 1 else inner[(x, y, step + 1)]
+                want_dep = (ref_ib - prev_ib[j]) if spl == 1 else None
+
+                def run():
+                    out, dd = np.zeros(10, np.float32), np.zeros(4, np.float32)
+                    assert l.rto_test_step(o._ctx, x, y, step, sin.ctypes.data_as(fp), out.ctypes.data_as(fp), dd.ctypes.data_as(fp)) == 0
+                    return out, dd
+
+                def agrees(res):
+                    st, dep = res
+                    ok = int(st[9:10].view(np.int32)[0]) == ref_depth(want) and np.allclose(st[6:9], want[6:9], rtol=1e-2, atol=1e-6)
+                    if want_dep is not None:
+                        ok = ok and dep[3] == want_dep[3] and np.allclose(dep[:3], want_dep[:3], rtol=1e-2, atol=2e-6 * max(1.0, float(ref_ib[3])))
+                    # ray origin / direction matter while the path goes on (depth > 0); the ground sphere's finite-difference
+                    # normal is noisy at 3e-3 in the reference itself
+                    return ok and (ref_depth(want) <= 0 or (np.allclose(st[0:3], want[0:3], rtol=1e-4, atol=2e-3) and np.allclose(st[3:6], want[3:6], atol=4e-2)))
+                res = run()
+                if not agrees(res):
+                    t.flips.append(((k, s_, x, y), classify(l, tag, f"launch {k} step {s_} of pixel {x},{y}", run, agrees)))
+                dep_sum += res[1]
+            if spl > 1 and not any(f[0][0] == k and f[0][2:] == (x, y) for f in t.flips):
+                want_dep = ref_ib - prev_ib[j]
+                assert dep_sum[3] == want_dep[3] and np.allclose(dep_sum[:3], want_dep[:3], rtol=1e-2, atol=2e-6 * max(1.0, float(ref_ib[3]))), (k, x, y)
+    return t.report()
+
+
+def ref_depth(rb_row):
+    """the fixture stores ray_buffer rows as floats: the depth column holds the integer's VALUE"""
+    return int(rb_row[9])
+
+
+def test_src_every_launch_from_the_references_state():
+    for name in ("ref_src.npz", "ref_src_spp4_black.npz", "ref_src_adaptive.npz"):
+        d, meta = load(name)
+        o = setup_variant(meta, d["env__u8"])
+        t = check_src_steps(lib(), o, d, meta)
+        assert t.n >= 0.5 * meta["launches"] * len(d["frame__pixels"]) * meta.get("steps_per_launch", 1) or meta.get("adaptive_sampling")
 
 
 def test_src_launches():
-    """K launches of the reference's render(): refresh on the first, pathtrace(), post_process() (src/renderer.py:25-32)"""
+    """K launches of the reference's render(): refresh on the first, pathtrace(), post_process() (src/renderer.py:25-32),
+    the oracle running on its OWN state from launch to launch (test_src_every_launch_from_the_references_state checks every
+    launch from the reference's state, without allowances): a pixel whose path drifts stays split, so what is bounded
+    here is the number of pixels that newly leave the reference's path per launch."""
     d, meta = load("ref_src.npz")
     o = setup_variant(meta, d["env__u8"])
     px = d["frame__pixels"]

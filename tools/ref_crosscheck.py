@@ -338,6 +338,9 @@ def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_thresh
 
     def russian_roulette(ray, i, j):                      # one bounce-step = one stream, keyed by the absolute step index
         rng.seek(i, j, state["step"] * spp + state["sub"])
+        if spp != 1:                                      # the ray state each bounce-step starts from (the launch records only its end)
+            rec.add("steps", px=i, py=j, step=state["step"] * spp + state["sub"],
+                    ray=np.concatenate([vec_np(ray.origin), vec_np(ray.direction), vec_np(ray.color), [np.float32(int(ray.depth))]]).astype(np.float32))
         state["sub"] += 1
         return o_rr(ray, i, j)
     pathtracer.russian_roulette = russian_roulette
@@ -418,7 +421,7 @@ def run_src(adaptive=False, out="ref_src.npz", K=24, grid=(24, 16), noise_thresh
         arrays = dict(frame__diff_buffer=np.array(hist_dbuf), frame__diff_pixels=np.array(hist_dpix))
         meta["adaptive_sampling"], meta["noise_threshold"] = 1, float(config.NOISE_THRESHOLD)
     elif spp != 1 or black:
-        arrays = {}
+        arrays = {k: v for k, v in arrays.items() if k.startswith("steps__")}
     meta["steps_per_launch"], meta["black_background"] = spp, int(black)
     arrays.update(frame__pixels=px, frame__ray_buffer=np.array(hist_ray), frame__image_buffer=np.array(hist_img),
                   frame__image_pixels=np.array(hist_pix), env__u8=env, env__processed=env_ref)
@@ -503,11 +506,58 @@ def run_script(tag, subdir, modname, cam_pos, step, grid, calls, env=False, fram
             rng.seek(ix[0], ix[1], state["sample"])
     _rt.on_index = on_index
     o_raytrace = m.raytrace
+    # in-situ observation of the script's own raycast / ray_surface_interaction / calc_normal / nearest_object while its
+    # render kernel runs (as run_v3 does): every event of every sample, so that a sample which differs in the oracle can be
+    # traced to its first differing event (tests/test_oracle_refpin.py, the decision classifier)
+    events = all(hasattr(m, n) for n in ("raycast", "ray_surface_interaction", "calc_normal", "nearest_object"))
+    cur = dict(raycasts=0, steps=0, n_steps=0, normal=np.zeros(3, np.float32))
+    if events:
+        o_raycast, o_rsi, o_normal, o_nearest = m.raycast, m.ray_surface_interaction, m.calc_normal, m.nearest_object
+
+        def obj_index(ob):          # which entry of the script's object table (matched by position: the table is small and distinct)
+            want = tuple(vec_np(ob.transform.position).tolist())
+            for i in range(m.objects.shape[0]):
+                if tuple(vec_np(m.objects[i].transform.position).tolist()) == want:
+                    return i
+            return -1
+
+        def nearest_object(p):
+            cur["n_steps"] += 1
+            return o_nearest(p)
+
+        def raycast(ray):
+            cur["n_steps"] = 0
+            r = o_raycast(ray)
+            cur["raycasts"] += 1
+            cur["steps"] += cur["n_steps"]
+            # HitRecord (cornell / bunny scripts) or the tuple (object, position, hit) of the scene_demo scripts
+            hit, pos, ob = (r[2], r[1], r[0]) if isinstance(r, tuple) else (r.hit, r.position, r.object)
+            rec.add("raycasts", px=rng.px, py=rng.py, sample=rng.sample, ro=vec_np(ray.origin), rd=vec_np(ray.direction),
+                    hit=bool(hit), pos=vec_np(pos), obj=obj_index(ob), steps=cur["n_steps"])
+            return r
+
+        def calc_normal(obj, p):
+            n = o_normal(obj, p)
+            cur["normal"] = vec_np(n)
+            return n
+
+        def ray_surface_interaction(ray, *args):       # (ray, record) or (ray, object, position)
+            n0 = rng.n
+            cin, din = vec_np(ray.color), vec_np(ray.direction)
+            out = o_rsi(ray, *args)
+            position, ob = (args[1], args[0]) if len(args) == 2 else (args[0].position, args[0].object)
+            rec.add("surface", px=rng.px, py=rng.py, sample=rng.sample, n0=n0, n1=rng.n, obj=obj_index(ob), pos=vec_np(position),
+                    dir_in=din, color_in=cin, normal=cur["normal"], dir_out=vec_np(out.direction), color_out=vec_np(out.color),
+                    origin_out=vec_np(out.origin))
+            return out
+        m.raycast, m.ray_surface_interaction, m.calc_normal, m.nearest_object = raycast, ray_surface_interaction, calc_normal, nearest_object
 
     def raytrace(ray):
         rin = (vec_np(ray.origin), vec_np(ray.direction))
+        cur["raycasts"] = cur["steps"] = 0
         out = o_raytrace(ray)
-        rec.add("samples", px=rng.px, py=rng.py, sample=rng.sample, ro=rin[0], rd=rin[1], color=vec_np(out.color), draws=rng.n)
+        extra = dict(raycasts=cur["raycasts"], steps=cur["steps"]) if events else {}
+        rec.add("samples", px=rng.px, py=rng.py, sample=rng.sample, ro=rin[0], rd=rin[1], color=vec_np(out.color), draws=rng.n, **extra)
         rng.seek(rng.px, rng.py, rng.sample + 1)
         return out
     m.raytrace = raytrace
