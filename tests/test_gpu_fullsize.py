@@ -35,6 +35,8 @@ def hip(scene, cfg, setup, variant):
     if variant == "jit_baked":
         g.set_option("jit", 2)            # strict: an error if the run-time instance cannot be used
         g.set_option("jit_bake", 1)
+    else:
+        g.set_option("jit", 0)            # the ahead-of-time instances, also where the library would compile one by itself
     return g
 
 

@@ -410,6 +410,8 @@ def test_full_size_cornell_1080p(variant, tmp_path, monkeypatch):
         if variant == "jit_baked":
             r.set_option("jit", 2)                       # strict: an error if the run-time instance cannot be used
             r.set_option("jit_bake", 1)
+        else:
+            r.set_option("jit", 0)
         return r
     want = _oracle_c2(sc, cfg)
     g = make()
