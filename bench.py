@@ -385,8 +385,8 @@ def main():
         }
         if wl.family != "src":
             split = m["primary_launches"] > 0
-            out["staging"] = {"bytes_per_step": int((16 + (8 if split else 0)) * c.samples),
-                              "note": "transient device memory of one step: one float4 per pixel-sample (+ one float2 primary record), "
+            out["staging"] = {"bytes_per_step": int((12 + (8 if split else 0)) * c.samples),
+                              "note": "transient device memory of one step: one 12-byte colour record per pixel-sample (+ one float2 primary record), "
                                       "reduced in sample order into image_buffer; reserved before the timed region (option reserve_spp)"}
         if multi:
             out["multi_gpu"] = multi

@@ -434,7 +434,7 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
 
 static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj, P.box_sig, P.objm); }
 
-// Staging (one float4 per item) and, for the primary split, the primary records (one float2 per item).
+// Staging (one 12-byte StageRec per item) and, for the primary split, the primary records (one float2 per item).
 // Grown on demand; hipMalloc of several GB takes 50..700 ms, so callers that time whole frames can
 // reserve up front (option "reserve_spp").
 // Returns RTPBR_ENOMEM (nothing allocated, no sticky HIP error) when the device has no room: the caller then renders
@@ -456,7 +456,7 @@ static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
     return RTPBR_OK;
 }
 static int ensure_staging(rtpbr_ctx* c, size_t items, bool split) {
-    if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(float4))) return r;
+    if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(StageRec))) return r;
     if (split)
         if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * sizeof(float2))) return r;
     return RTPBR_OK;
@@ -661,7 +661,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         int left = n;
         while (left > 0) {
             const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
-            long long per_spp = (long long)P.np * (long long)(sizeof(float4) + (split_ok ? sizeof(float2) : 0));
+            long long per_spp = (long long)P.np * (long long)(sizeof(StageRec) + (split_ok ? sizeof(float2) : 0));
             long long kmax = c->staging_bytes / per_spp;
             if (kmax < 1) kmax = 1;
             // keep total_items within 32 bits
@@ -977,7 +977,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 1) return fail(RTPBR_EINVAL, "reserve_spp must be >= 1");
         if (int r = set_dev(c)) return r;
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
-        long long per_spp = (long long)c->P.np * (long long)(sizeof(float4) + (split_ok ? sizeof(float2) : 0));
+        long long per_spp = (long long)c->P.np * (long long)(sizeof(StageRec) + (split_ok ? sizeof(float2) : 0));
         long long kmax = c->staging_bytes / per_spp;
         long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)c->P.np;
         if (k32 < 1) k32 = 1;

@@ -87,7 +87,7 @@ struct rtpbr_ctx {
     ObjFull* objfull = nullptr;
     float4* env = nullptr;
     float* bunny = nullptr;
-    float4* stage = nullptr;
+    float* stage = nullptr;          // 12 bytes per pixel-sample of a launch (rt::StageRec)
     size_t stage_cap = 0;  // bytes
     float2* primary = nullptr;
     size_t primary_cap = 0;

@@ -34,27 +34,32 @@ __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
     if (!pixel_of(P, q, x, y)) return;
     float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
     float4 acc = *dst;
-    // a pixel's K records are contiguous (item-linear staging): fetch them 8 at a time (128 B per
-    // lane, every cache line is touched once) and add them strictly in sample order
-    const float4* src = P.stage + (size_t)q * (size_t)P.K;
+    // a pixel's K records (12 bytes each) are contiguous (item-linear staging): fetch them 8 at a time (96 B per lane as
+    // six 16-byte loads when the pixel's run starts on a 16-byte boundary, i.e. K % 4 == 0) and add them strictly in
+    // sample order
+    const float* src = P.stage + (size_t)q * (size_t)P.K * 3u;
     int k = 0;
-    for (; k + 8 <= P.K; k += 8) {
-        float4 c[8];
+    if ((P.K & 3) == 0) {
+        for (; k + 8 <= P.K; k += 8) {
+            float4 v[6];
+            const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)k * 3u);
 #pragma unroll
-        for (int i = 0; i < 8; i++) c[i] = src[k + i];
+            for (int i = 0; i < 6; i++) v[i] = s4[i];
+            const float f[24] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w,
+                                 v[3].x, v[3].y, v[3].z, v[3].w, v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            acc.x += c[i].x;
-            acc.y += c[i].y;
-            acc.z += c[i].z;
-            acc.w += 1.0f;
+            for (int i = 0; i < 8; i++) {
+                acc.x += f[3 * i];
+                acc.y += f[3 * i + 1];
+                acc.z += f[3 * i + 2];
+                acc.w += 1.0f;
+            }
         }
     }
     for (; k < P.K; k++) {
-        float4 c = src[k];
-        acc.x += c.x;
-        acc.y += c.y;
-        acc.z += c.z;
+        acc.x += src[3 * k];
+        acc.y += src[3 * k + 1];
+        acc.z += src[3 * k + 2];
         acc.w += 1.0f;
     }
     *dst = acc;

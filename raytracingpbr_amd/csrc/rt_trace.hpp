@@ -108,9 +108,11 @@ RT_D void shade_miss(const Params& P, PathRay& R, uint32_t& n_sky) {
 }
 
 // Staging layout [q][k] = item-linear: the items a wave has in flight are (nearly) consecutive,
-// so its 16-byte stores fall into the same few cache lines and merge in L2 before they reach HBM.
-RT_D void write_sample(const Params& P, uint32_t item, vec3 col, float w) {
-    P.stage[item] = make_float4(col.x, col.y, col.z, w);
+// so its stores fall into the same few cache lines and merge in L2 before they reach HBM.  A record is the sample's
+// three colour words, 12 bytes (round 3; it was a float4 whose fourth word nobody read: the count a sample adds is 1 by
+// definition and padding pixels of an edge tile are known from the geometry, so they are not written at all).
+RT_D void write_sample(const Params& P, uint32_t item, vec3 col) {
+    reinterpret_cast<StageRec*>(P.stage)[item] = StageRec{col.x, col.y, col.z};
 }
 
 // renderer.py:32-35: jitter, get_ray, color = 1, then roulette at i = 0 (p = 0, the draw is consumed).
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
             finished = true;
         }
         if (finished) {
-            write_sample(P, R.item, R.col, 1.0f);
+            write_sample(P, R.item, R.col);
             n_samples++;
             L.state = ST_IDLE;
         }
@@ -224,8 +226,8 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
                 if (got) {
                     int r = start_item(P, R);
                     if (r == 1) alive = true;
-                    else if (r == 0) { write_sample(P, R.item, R.col, 1.0f); n_samples++; }
-                    else write_sample(P, R.item, mk(0, 0, 0), 0.0f);   // padding pixel: stays idle until the next refill
+                    else if (r == 0) { write_sample(P, R.item, R.col); n_samples++; }
+                    // (r < 0: padding pixel of an edge tile, nothing to record: the lane stays idle until the next refill)
                 } else if (wr.drained) {
                     L.state = ST_EXHAUSTED;
                 }
@@ -588,7 +590,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     }
                 }
                 w_sky += (uint32_t)__popcll(__ballot(sky1 != 0));
-                if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col, 1.0f);
+                if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col);
                 w_samples += (uint32_t)__popcll(__ballot((st == SL_HIT || st == SL_MISS) && !alive));
                 if (st == SL_HIT || st == SL_MISS) st = SL_EMPTY;
                 // refill free slots with fresh pixel-samples.  start_item costs ~200 instructions and a shading pass frees
@@ -614,8 +616,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                         } else {
                             alive = true;
                         }
-                    } else if (r == 0) write_sample(P, R.item, R.col, 1.0f);
-                    else write_sample(P, R.item, mk(0, 0, 0), 0.0f);
+                    } else if (r == 0) write_sample(P, R.item, R.col);
                     roulette0 = r == 0;
                 }
                 w_samples += (uint32_t)__popcll(__ballot(roulette0));

@@ -7,7 +7,7 @@
 //     consumed as scalar operands and cost no VGPRs and no LDS bandwidth.
 //   ObjFull[n] (HBM -> LDS once per workgroup): transform + material of every object,
 //     gathered PER LANE by hit-object index in the shading phase (T4).
-//   stage (HBM): one float4 per pixel-sample of the current sub-launch, [q][k] (k fastest),
+//   stage (HBM): one StageRec (12 B) per pixel-sample of the current sub-launch, [q][k] (k fastest),
 //     reduced in sample order into image_buffer (T7) by the accumulate kernel.
 #pragma once
 #include <stdint.h>
@@ -98,6 +98,10 @@ struct CamFrame {
     float inv_w, inv_h;
 };
 
+// one staged sample: its three colour words (the count it adds is 1 by definition)
+struct __attribute__((packed, aligned(4))) StageRec { float r, g, b; };
+static_assert(sizeof(StageRec) == 12, "staging record is 12 bytes");
+
 struct Counters {
     unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
     // neural SDF (matrix-core path): MLP passes over a wave, and the ray-evaluations those passes were needed for
@@ -132,7 +136,7 @@ struct Params {
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)
     int32_t mlp_full;       // bunny: compute both 32-slot halves when at least this many wait, else the first 32
     // pointers
-    float4* stage;
+    float* stage;           // 3 floats per work item (StageRec)
     float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
     uint32_t box_sig;       // host side: which RT_BOX_SIGNATURES instance to launch (0 = general)

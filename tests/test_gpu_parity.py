@@ -8,6 +8,8 @@ exactly-rounded operation sequence and the same counter-based random stream; ima
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -576,6 +578,71 @@ def test_edge_cases_match_oracle():
     assert np.array_equal(bits(merged), bits(full.image_buffer))
     with pytest.raises(RtpbrError):
         g.set_scene(Scene(objs + objs[:1], False, sc.camera))          # 33 objects > RTPBR_MAX_OBJECTS
+
+
+_FAKE_RCCL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from cases import case_by_name
+from raytracingpbr_amd import Renderer
+from raytracingpbr_amd.distributed import gather_group, rccl_group
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+case = case_by_name("cornell_v3_8b_wide")
+W, H = case.cfg.width, case.cfg.height
+ref = Renderer(case.scene, case.cfg); ref.sample(4); want = ref.image_buffer
+
+def ranks(world, tile, keep=None):
+    rs = keep or []
+    while len(rs) < world:
+        rs.append(Renderer(case.scene, case.cfg))
+    for i, r in enumerate(rs[:world]):
+        r.set_tiles(tile[0], tile[1], i, world)
+        r.refresh(); r.set_option("sample_base", 0)
+        r.sample(4)
+    return rs
+
+# G contexts of ONE process on one device: init_all + the grouped gather (SURVEY 8(e)'s single-process design)
+for world, tile in ((2, (16, 16)), (3, (16, 16)), (5, (8, 8)), (8, (32, 20))):
+    rs = ranks(world, tile)
+    rccl_group(rs)
+    assert rs[1].rccl_info()[:2] == (world, 1)
+    gather_group(rs)
+    rs[0].sync()
+    assert np.array_equal(bits(rs[0].image_buffer), bits(want)), (world, tile)
+    # a second gather after more samples: buffers are reused, the frame is still the untiled one
+    for r in rs: r.sample(2)
+    gather_group(rs); rs[0].sync()
+    ref2 = Renderer(case.scene, case.cfg); ref2.sample(6)
+    assert np.array_equal(bits(rs[0].image_buffer), bits(ref2.image_buffer)), (world, tile)
+    for r in rs: r.close()
+# the receive side must grow when the WORLD grows while the local share stays the same (96x54 in 48x27 tiles = 4 tiles:
+# two local tiles for world 2 and for world 3) — rank 0's buffer was sized for 2 ranks first
+rs = ranks(2, (48, 27))
+rccl_group(rs); gather_group(rs); rs[0].sync()
+assert np.array_equal(bits(rs[0].image_buffer), bits(want))
+rs = ranks(3, (48, 27), keep=rs)
+rccl_group(rs); gather_group(rs); rs[0].sync()
+assert np.array_equal(bits(rs[0].image_buffer), bits(want))
+print("FAKE-RCCL-OK")
+"""
+
+
+def test_multi_rank_gather_path_on_one_gpu_with_an_in_process_rccl_stand_in():
+    """Everything of the N > 1 C-ABI path except RCCL itself, with N up to 8 on this box's one GPU: per-rank packing, the
+    receive offsets, rank 0's unpack loop over the other ranks, the grouped launch of G contexts, buffer growth when the
+    world changes.  RTPBR_RCCL_LIB points the library at tests/stubs/libfake_rccl.so (device-to-device copies with RCCL's
+    stream semantics, built by __graft_entry__.build()); the gathered frame must equal the untiled one bit for bit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "stubs", "libfake_rccl.so")
+    if not os.path.exists(stub):
+        subprocess.run(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "stubs", "fake_rccl.cpp"),
+                        "-L/opt/rocm/lib", "-lamdhip64", "-o", stub], check=True)
+    env = dict(os.environ, RTPBR_RCCL_LIB=stub)
+    out = subprocess.run([sys.executable, "-c", _FAKE_RCCL_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "FAKE-RCCL-OK" in out.stdout, out.stderr[-3000:]
 
 
 def test_rccl_gather_through_the_c_abi():
