@@ -45,7 +45,9 @@ run("C4_tokyo_ibl_4k_512spp_rank0of4", src_scene(aspect=16 / 9, tokyo=True), Con
 tw, th = default_tile(7680, 4320, 8)
 spp5 = int(os.environ.get("C5_SPP", "4096"))
 run(f"C5_cornell_8k_{spp5}spp_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), spp5, tiles=(tw, th, 0, 8), chunk=256)
-run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4, chunk=64)
+run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4)
+run("src_1080p_persistent_256steps", src_scene(aspect=16 / 9), Config.src(1920, 1080, 0, 1), 256, env=env3k, envexp=1.4)
+run("src_4k_persistent_256steps", src_scene(aspect=16 / 9), Config.src(3840, 2160, 0, 1), 256, env=env3k, envexp=1.4)
 if not LIST:
     path = os.path.join(ROOT, "gpurun_out", "configs.json")
     if only and os.path.exists(path):            # per-config invocations accumulate into one file

@@ -14,7 +14,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smo
 python bench.py --steps 3 --warmup 1 2>$OUT/bench_$TAG.err | tee $OUT/bench_$TAG.json
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --keep-jit-cache"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- $BENCH > $OUT/prof_bench_$TAG.json 2> $OUT/prof_$TAG.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$TAG -o pmc -- $BENCH > $OUT/pmc_fetch_bench_$TAG.json 2> $OUT/pmc_fetch_$TAG.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$TAG -o pmc -- $BENCH > $OUT/pmc_write_bench_$TAG.json 2> $OUT/pmc_write_$TAG.err
