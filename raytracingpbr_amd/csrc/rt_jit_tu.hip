@@ -30,7 +30,7 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P)
     primary_rays_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(Q);
 }
 // src/ persistent-ray form (pathtrace() of src/pathtracer.py:94-103): `steps` bounce-steps per pixel and launch
-extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES) rt_jit_persistent_pool(const Params P, int steps) {
+extern "C" __global__ void __launch_bounds__(256, (RT_JIT_WAVES > 5 ? 5 : RT_JIT_WAVES)) rt_jit_persistent_pool(const Params P, int steps) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);
     persistent_pool_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q, steps);

@@ -3,7 +3,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracingpbr_amd import Config, Renderer, cornell_box
 W, H = 1920, 1080
+# run as: RTPBR_JIT_EXTRA_FLAGS=-DRT_DEBUG_PHASE python tools/gpu_dbg_phase.py   (the instrumented build of the run-time kernels)
+assert "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""), "set RTPBR_JIT_EXTRA_FLAGS=-DRT_DEBUG_PHASE"
 r = Renderer(cornell_box("v3", aspect=W / H), Config.cornell_v3(W, H, 0, 8))
+r.set_option("jit", 2); r.set_option("jit_bake", 1)
 r.sample(64); r.sync()
 r.refresh(); r.sample(64); c = r.counters(); tr, tot, n = r.last_sample_ms()
 B, D, A = r.counter("mlp_wave_evals"), c.sky_lookups, r.counter("mlp_lane_evals")
