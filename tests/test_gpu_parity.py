@@ -251,6 +251,42 @@ def test_persistent_form_schedulers_agree():
         r.close()
 
 
+def test_persistent_form_tile_partition():
+    """src/ pipeline under the multi-GPU tile partition: every virtual rank advances ONLY its own pixels (image_buffer and
+    ray_buffer elsewhere stay untouched), edge tiles are padded, and the union of the ranks' pixels is the untiled run bit
+    for bit — through the pool kernel's single-pass and multi-pass (residency) walks, and against the oracle's own tiled run."""
+    case = case_by_name("src_persistent")
+    W, H = case.cfg.width, case.cfg.height
+    full = Renderer(case.scene, case.cfg)
+    case.setup(full)
+    full.sample(20)
+    want_ib, want_rb = full.image_buffer, full.ray_buffer
+    for world, tile, opts in ((3, (20, 16), {}), (2, (32, 32), {"grid_blocks": 1, "residency": 4}), (5, (8, 8), {"scheduler": 0})):
+        lay = TileLayout(W, H, tile[0], tile[1], world)
+        owner = lay.owner_map()
+        got_ib, got_rb = np.zeros_like(want_ib), np.zeros_like(want_rb)
+        for rank in range(world):
+            r = Renderer(case.scene, case.cfg)
+            case.setup(r)
+            for k, v in opts.items():
+                r.set_option(k, v)
+            r.set_tiles(tile[0], tile[1], rank, world)
+            r.sample(12)
+            r.sample(8)
+            ib, rb = r.image_buffer, r.ray_buffer
+            mine = owner == rank
+            assert np.all(ib[~mine] == 0)                                   # nobody else's pixels were touched
+            got_ib[mine], got_rb[mine] = ib[mine], rb[mine]
+            if rank == 1:
+                o = OracleRenderer(case.scene, case.cfg)
+                case.setup(o)
+                o.set_tiles(tile[0], tile[1], rank, world)
+                o.sample(20)
+                assert np.array_equal(bits(ib), bits(o.image_buffer)) and np.array_equal(bits(rb[mine]), bits(o.ray_buffer[mine]))
+            r.close()
+        assert np.array_equal(bits(got_ib), bits(want_ib)) and np.array_equal(bits(got_rb), bits(want_rb)), (world, tile, opts)
+
+
 def test_tile_partition_pack_unpack_is_bit_exact():
     """G virtual ranks on one device: each renders its tiles, packs them on the device, rank 0
     unpacks -> identical to the untiled frame (SURVEY.md §8(e) testability row)."""
