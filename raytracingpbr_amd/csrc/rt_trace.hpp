@@ -944,12 +944,12 @@ RT_D void march_step_src(const Params& P, Lane& L) {
 // the caller).  Pays when FEW lanes march — a launch ends with every wave marching the handful of pixels whose raycasts
 // graze the ground for hundreds of steps, and those are near ONE object: the other six are skipped for the whole wave.
 template <int KIND, int NOBJ, uint32_t SIG>
-RT_D void march_step_src_culled(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ > 0 ? NOBJ : 1]) {
+RT_D void march_step_src_culled(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ > 0 ? NOBJ : 1], uint32_t* dbg_evaluated = nullptr) {
     const bool active = L.state == ST_MARCH;
     float ld = L.dist;
     int idx;
     float dist;
-    nearest_culled<KIND, NOBJ, SIG>(P, L.o, L.t, active, ub, lb, idx, dist);
+    nearest_culled<KIND, NOBJ, SIG>(P, L.o, L.t, active, ub, lb, idx, dist, dbg_evaluated);
     float moved = 0.0f;
     if (active) {
         L.idx = idx;
@@ -1093,6 +1093,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
     unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_sparse_iters = 0;
+    uint32_t dbg_evaluated = 0;     // objects evaluated by the culled steps (wave level)
 #endif
 
     for (;;) {
@@ -1236,7 +1237,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             }
         }
 
-        RT_PHASE(tD)
+        RT_PHASE(tB)
         // ================================================================ march
         {
             int n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -1257,16 +1258,26 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #pragma unroll
                     for (int i = 0; i < NOBJ; i++) lb[i] = -1.0f;
                     float ub = 3.0e38f;
+#ifdef RT_DEBUG_PHASE
+                    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
                     do {
 #ifdef RT_DEBUG_PHASE
                         dbg_march_iters++;
                         dbg_march_lanes += (unsigned)n_march;
                         dbg_sparse_iters++;
 #endif
+#ifdef RT_DEBUG_PHASE
+                        march_step_src_culled<KIND, NOBJ, SIG>(P, L, ub, lb, &dbg_evaluated);
+#else
                         march_step_src_culled<KIND, NOBJ, SIG>(P, L, ub, lb);
+#endif
                         n_march = __popcll(__ballot(L.state == ST_MARCH));
                         n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
                     } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+#ifdef RT_DEBUG_PHASE
+                    tD += __builtin_readcyclecounter() - ts0;      // (cycles of the sparse march loops, reported in place of the dispatch phase)
+#endif
                 }
             } else {
                 do {
@@ -1285,11 +1296,11 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
     if (lane == 0) {   // cycles per phase and wave lifetime (>> 10), passes, slots shaded, march iterations, lanes marching
         atomicAdd(&P.counters->dbg[0], tB >> 10);
-        atomicAdd(&P.counters->dbg[1], dbg_sparse_iters);      // (march iterations that ran the culled step)
+        atomicAdd(&P.counters->dbg[1], dbg_sparse_iters | ((tD >> 10) << 32));      // march iterations that ran the culled step; their cycles >> 10 in the high word
         atomicAdd(&P.counters->dbg[2], tA >> 10);
         atomicAdd(&P.counters->dbg[3], (__builtin_readcyclecounter() - t_start) >> 10);
         atomicAdd(&P.counters->dbg[4], dbg_passes);
-        atomicAdd(&P.counters->dbg[5], dbg_shaded);
+        atomicAdd(&P.counters->dbg[5], dbg_shaded | ((unsigned long long)dbg_evaluated << 40));
         atomicAdd(&P.counters->dbg[6], dbg_march_iters);
         atomicAdd(&P.counters->dbg[7], dbg_march_lanes);
     }

@@ -35,8 +35,10 @@ if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
                           "mean_march_steps_per_pixel": round(c.march_steps / (W * H), 1)}), flush=True)
         raise SystemExit
     waves = max(1, round(W * H / 128 / 4 + 0.5)) * 4
-    print(json.dumps({"phase_Mcycles": {"B": d[0] >> 10, "march": d[2] >> 10, "wave_life_sum": d[3] >> 10},
-                      "passes": d[4], "slots_shaded_per_pass": round(d[5] / max(d[4], 1), 2), "march_iters": d[6], "sparse_iters": d[1],
+    print(json.dumps({"phase_Mcycles": {"B_and_dispatch": d[0] >> 10, "march": d[2] >> 10, "wave_life_sum": d[3] >> 10},
+                      "passes": d[4], "slots_shaded_per_pass": round((d[5] & ((1 << 40) - 1)) / max(d[4], 1), 2),
+                      "objects_evaluated_per_sparse_iter": round((d[5] >> 40) / max(d[1] & 0xffffffff, 1), 2), "march_iters": d[6], "sparse_iters": d[1] & 0xffffffff, "cycles_per_sparse_iter": round(((d[1] >> 32) << 10) / max(d[1] & 0xffffffff, 1)),
+                      "cycles_per_dense_iter": round(((d[2] - (d[1] >> 32)) << 10) / max(d[6] - (d[1] & 0xffffffff), 1)),
                       "lanes_per_march_iter": round(d[7] / max(d[6], 1), 2),
                       "cycles_per_pass": round((d[0] << 10) / max(d[4], 1)), "cycles_per_march_iter": round((d[2] << 10) / max(d[6], 1))}), flush=True)
 r.close()
