@@ -16,6 +16,9 @@ for seed in range(lo, hi):
     co = o.counters()
     variants = [{}, {"primary_split": 2}]
     if seed % 3 == 0: variants.append({"jit": 1, "jit_bake": seed % 2})      # run-time instance where the scene is eligible
+    if cfg.kernel_form == 1:        # src/ form: the pool kernel's ownership / residency / culling choices, the lock-step kernel
+        variants += [{"scheduler": 0}, {"grid_blocks": 1, "residency": 2}, {"grid_blocks": 3, "residency": 8, "sparse_lanes": 64, "jit": 1},
+                     {"sparse_lanes": 0, "shade_lanes": 17, "swap_lanes": 5}, {"jit": 1, "jit_bake": 1, "grid_blocks": 2, "residency": 1}]
     for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)
