@@ -575,7 +575,7 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
         // !(lb > bound); __all / __ballot cost two more VALU instructions per object here)
         if ((__builtin_amdgcn_fcmpf(lb[i], bound, 13) & act_mask) == 0ull) return;
         const ObjM o = load_obj<SIG, i>(tab);
-#ifdef RT_DEBUG_PHASE
+#if defined(RT_DEBUG_PHASE) || defined(RT_DEBUG_CULL)
         if (dbg_evaluated) (*dbg_evaluated)++;
 #endif
         float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i), jit_type(i)));

@@ -523,6 +523,13 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     auto f2u = [](float x) { return __builtin_bit_cast(uint32_t, x); };
     auto u2f = [](uint32_t x) { return __builtin_bit_cast(float, x); };
 
+#ifdef RT_DEBUG_CULL
+    float dbg_lb[NOBJ > 0 ? NOBJ : 1];
+#pragma unroll
+    for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) dbg_lb[i] = -1.0f;
+    float dbg_ub = 3.0e38f;
+    uint32_t dbg_cull_eval = 0, dbg_cull_all = 0;
+#endif
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter();
     unsigned long long dbg_march_lanes = 0, dbg_march_steps = 0, dbg_shade_lanes = 0, dbg_shade_passes = 0;
@@ -733,6 +740,37 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     dbg_march_lanes += (unsigned)n_march;
                     dbg_march_steps += 1;
 #endif
+#ifdef RT_DEBUG_CULL
+                    // MEASUREMENT BUILD (-DRT_DEBUG_CULL): how many (wave-step, object) evaluations would vanish if the pool
+                    // kernel's march loop kept per-lane Lipschitz bounds and skipped an object when NO marching lane needs it
+                    // (what primary_rays does for its coherent waves)?  The culled step is exact, so results do not change;
+                    // dbg[0] += objects evaluated, dbg[1] += objects x wave-steps.
+                    if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) {
+                        const bool active = L.state == ST_MARCH;
+                        if (active && L.steps_left == P.cfg.max_raymarch) {      // a ray that starts its raycast knows nothing yet
+#pragma unroll
+                            for (int i = 0; i < NOBJ; i++) dbg_lb[i] = -1.0f;
+                            dbg_ub = 3.0e38f;
+                        }
+                        vec3 pos = fma3(L.t, L.d, L.o);
+                        const float t_before = L.t;
+                        int idx;
+                        float dist;
+                        uint32_t ev = 0;
+                        nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, dbg_ub, dbg_lb, idx, dist, &ev);
+                        dbg_cull_eval += ev;
+                        dbg_cull_all += NOBJ;
+                        float moved = 0.0f;
+                        if (active) {
+                            L.t_eval = L.t;
+                            march_update(P, L, idx, dist);
+                            moved = fabs_(L.t - t_before) * 1.000001f;
+                            dbg_ub = dist + moved;
+                        }
+#pragma unroll
+                        for (int i = 0; i < NOBJ; i++) dbg_lb[i] -= moved;
+                    } else
+#endif
                     if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
                 }
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -750,6 +788,12 @@ RT_D void trace_paths_pool_impl(const Params& P) {
         atomicAdd(&P.counters->mlp_lane_evals, tA >> 10);
         atomicAdd(&P.counters->hits, dbg_march_lanes);          // (replaces the hit count in this build)
         atomicAdd(&P.counters->deposits, dbg_march_steps);
+    }
+#endif
+#ifdef RT_DEBUG_CULL
+    if (lane == 0) {
+        atomicAdd(&P.counters->dbg[0], (unsigned long long)dbg_cull_eval);
+        atomicAdd(&P.counters->dbg[1], (unsigned long long)dbg_cull_all);
     }
 #endif
     if (KIND == KIND_BUNNY && lane == 0 && w_mlp_wave) {
