@@ -506,6 +506,20 @@ def test_bench_multirank_path_functional(workload):
     assert mg["bytes_gathered_per_rank"] > 0 and "host" in mg["transport"]
 
 
+@pytest.mark.parametrize("workload", ["c1", "c3", "c4", "c5", "src"])
+def test_bench_every_workload_single_gpu_contract(workload):
+    """bench.py --workload X at N = 1 (small frame): the line keeps the driver's contract and carries its own FLOP model"""
+    j = _run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", workload, "--width", "320", "--height", "180", "--spp", "8",
+                    "--no-cpu-baseline", "--no-configs"])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["higher_is_better"] is True
+    assert j["unit"] == ("Mbounce-steps/s" if workload == "src" else "Msamples/s") and j["dtype"] == "f32" and j["data"] == "synthetic"
+    r = j["roofline"]
+    assert r["bound"] == "valu" and r["peak"] == 157.3 and 0 < r["frac"] < 1 and r["algorithmic_flop_per_unit"] > 1000
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] >= 2
+    assert abs(j["value"] - 320 * 180 * 8 * 2 / (j["ms_per_step"] * 2 / 1e3) / 1e6) < 0.02 * j["value"]
+    assert j["config"]["kernels"].startswith("run-time compiled") and j["jit"]["first_use_s"] > 0
+
+
 def test_bench_default_transport_is_the_c_abi_rccl_gather():
     """The transport a SCALE run takes by default — rtpbr_rccl_unique_id / rccl_init / gather_tiles, i.e. ROCm's librccl
     behind the C ABI — driven by bench.py itself on this box's one GPU (a 1-rank communicator): RCCL reports the rank
