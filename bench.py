@@ -246,6 +246,10 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(d, src=0)
         os.environ["RTPBR_JIT_CACHE"] = d[0]
+        if rank == 0:
+            import atexit
+            import shutil
+            atexit.register(shutil.rmtree, d[0], True)      # the code objects of this run only
 
     from raytracingpbr_amd import workloads
     from raytracingpbr_amd.distributed import TileGather
