@@ -191,8 +191,8 @@ def side_config(name, a, device, rank0_of=1):
     bounded sample count, with its own FLOP model"""
     from raytracingpbr_amd import workloads
     from raytracingpbr_amd.tiles import default_tile
-    bounded = {"c1": 16, "c3": 256, "c4": 256, "c5": 128, "src": 256}[name]
-    wl = workloads.get(name, spp=bounded)
+    bounded = {"c1": 16, "c3": 256, "c4": 256, "c5": 128, "src": 256, "src_4k": 256}[name]
+    wl = workloads.get("src", 3840, 2160, bounded) if name == "src_4k" else workloads.get(name, spp=bounded)
     r = make_renderer(wl, device, a, jit=not a.no_jit)
     W, H = wl.cfg.width, wl.cfg.height
     share = ""
@@ -208,7 +208,7 @@ def side_config(name, a, device, rank0_of=1):
     m = measure(wl, r, steps, 1)
     c, fpu, kernel_s, tflops = roofline_of(wl, r, m, steps, W * H)
     units = c.samples * steps
-    out = {"workload": wl.title.replace(f"{workloads.get(name).spp} spp", f"{wl.spp} spp") + share,
+    out = {"workload": wl.title.replace(f"{workloads.get(wl.name).spp} spp", f"{wl.spp} spp") + share,
            "value": round(units / m["dt"] / 1e6, 1), "unit": wl.unit, "units_per_step": c.samples, "steps": steps,
            "ms_per_step": round(m["dt"] / steps * 1e3, 3), "kernel_ms_per_step": round(kernel_s * 1e3, 3),
            "algorithmic_flop_per_unit": round(fpu), "achieved_tflops": round(tflops, 2), "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
@@ -414,7 +414,7 @@ def main():
                     r2.close()
             out["jit"] = jit
             if a.workload == "c2" and not a.no_configs:
-                out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c4", "c5", "src")}
+                out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c4", "c5", "src", "src_4k")}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(out), flush=True)
