@@ -566,6 +566,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
             }
             key.cull = P.cull_ok;
+            key.form = persistent ? 1 : 0;
             if (jit_bunny) key.sig = 0;
             key.waves = c->kind == KIND_BOXES ? 6 : c->kind == KIND_BUNNY ? 4 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
             if (c->jit_waves > 0) key.waves = c->jit_waves;

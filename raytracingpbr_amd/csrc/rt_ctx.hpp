@@ -32,6 +32,7 @@ struct RtJitKey {
     unsigned long long types;   // (shape type + 1) in 4 bits per object
     unsigned sig;               // rotation class in 3 bits per object
     int cull, waves;
+    int form;                   // 0 = complete-path kernels, 1 = persistent-ray kernels (only those are compiled)
     int baked;                  // 1: the march table and the render configuration are baked into the code object
     const unsigned* table;      // n_obj x 16 words (ObjM blocks)
     unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed

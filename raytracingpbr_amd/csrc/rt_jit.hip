@@ -238,8 +238,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
             for (char ch : f) th = (th ^ (unsigned char)ch) * 1099511628211ull + 1;
     }
     char name[256];
-    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, (unsigned long long)th, (unsigned long long)sh);
+    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, (unsigned long long)th, (unsigned long long)sh);
     const std::string cdir = cache_dir();
     if (cdir.empty())
         return rt_fail(RTPBR_ESTATE, "run-time compilation is off: no cache directory that is owned by this user and closed to others "
@@ -286,7 +286,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         fclose(f);
         table_def = "-DRT_JIT_TABLE_FILE=\"" + tfile + "\"";
     }
-    char d[6][64];
+    char d[7][64];
+    snprintf(d[6], 64, "-DRT_JIT_FORM=%d", key.form);
     snprintf(d[0], 64, "-DRT_JIT_KIND=%d", key.kind);
     snprintf(d[1], 64, "-DRT_JIT_NOBJ=%d", key.n_obj);
     snprintf(d[2], 64, "-DRT_JIT_TYPES=0x%llxull", (unsigned long long)key.types);
@@ -296,7 +297,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     // the flags of raytracingpbr_amd/build.py: same code generation as the ahead-of-time library
     std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
                                      "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-unused-value",
-                                     d[0], d[1], d[2], d[3], d[4], d[5], dir + "/rt_jit_tu.hip", "-o", tpath};
+                                     d[0], d[1], d[2], d[3], d[4], d[5], d[6], dir + "/rt_jit_tu.hip", "-o", tpath};
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     argv.insert(argv.begin() + 10, extra.begin(), extra.end());
     const int rc = run(argv, log);
@@ -351,8 +352,8 @@ static void evict_modules() {
 // The instance of `key` on c's device, PINNED (rt_jit_release when the context stops using it).
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     char id[224];
-    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, (unsigned long long)baked_hash(key));
+    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_f%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, (unsigned long long)baked_hash(key));
     if (const char* e = getenv("RTPBR_JIT_EXTRA_FLAGS")) snprintf(id + strlen(id), sizeof id - strlen(id), "_x%zx", std::hash<std::string>()(e));
     {
         std::unique_lock<std::mutex> lock(g_mu);
@@ -405,12 +406,16 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     RtJitModule* m = new RtJitModule();
     m->device = c->device;
     if (e == hipSuccess) e = hipModuleLoadData(&m->module, image.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&m->trace, m->module, "rt_jit_trace");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m->primary, m->module, "rt_jit_primary");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_pool, m->module, "rt_jit_persistent_pool");
-    if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_steps, m->module, "rt_jit_persistent_steps");
-    if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->trace_blocks_per_cu, m->trace, 256, 0);
-    if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->persistent_blocks_per_cu, m->persistent_pool, 256, 0);
+    if (key.form != 1) {
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->trace, m->module, "rt_jit_trace");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->primary, m->module, "rt_jit_primary");
+        if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->trace_blocks_per_cu, m->trace, 256, 0);
+    }
+    if (key.form != 0) {
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_pool, m->module, "rt_jit_persistent_pool");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_steps, m->module, "rt_jit_persistent_steps");
+        if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->persistent_blocks_per_cu, m->persistent_pool, 256, 0);
+    }
     if (e != hipSuccess) {
         if (m->module) (void)hipModuleUnload(m->module);
         delete m;
@@ -448,6 +453,7 @@ int rt_jit_launch_steps(hipFunction_t f, const Params& P, int steps, unsigned gr
 extern "C" int rtpbr_test_jit_build(int kind, int n_obj, unsigned long long types, unsigned sig, int cull, int waves, char* path_out, size_t cap) {
     RtJitKey k{};
     k.kind = kind, k.n_obj = n_obj, k.types = types, k.sig = sig, k.cull = cull, k.waves = waves;
+    k.form = 2;                                       // all four kernels: "does it build" covers both forms
     std::string p;
     if (int r = rt_jit_build(k, &p, nullptr)) return r;
     if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());

@@ -19,6 +19,12 @@
 namespace rt {
 // the neural-SDF kinds keep their own object handling (one object, table row 0): no unrolled object loop
 constexpr int TU_NOBJ = (RT_JIT_KIND == KIND_BUNNY || RT_JIT_KIND == KIND_MIXED) ? 0 : RT_JIT_NOBJ;
+// RT_JIT_FORM: 0 = the complete-path kernels only, 1 = the persistent-ray kernels only (halves the compile time of a scene's
+// first use), anything else = all four
+#ifndef RT_JIT_FORM
+#define RT_JIT_FORM 2
+#endif
+#if RT_JIT_FORM != 1
 extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES) rt_jit_trace(const Params P) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);
@@ -29,6 +35,8 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P)
     RT_JIT_BAKE_PARAMS(Q);
     primary_rays_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG, (RT_JIT_CULL != 0)>(Q);
 }
+#endif
+#if RT_JIT_FORM != 0
 // src/ persistent-ray form (pathtrace() of src/pathtracer.py:94-103): `steps` bounce-steps per pixel and launch
 extern "C" __global__ void __launch_bounds__(256, (RT_JIT_WAVES > 5 ? 5 : RT_JIT_WAVES)) rt_jit_persistent_pool(const Params P, int steps) {
     Params Q = P;
@@ -40,4 +48,5 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_persistent_steps(const 
     RT_JIT_BAKE_PARAMS(Q);
     persistent_steps_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q, steps);
 }
+#endif
 }  // namespace rt
