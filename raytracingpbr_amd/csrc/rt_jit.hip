@@ -84,7 +84,7 @@ bool read_file(const std::string& path, std::vector<char>& out) {
 
 // FNV-1a over the sources the translation unit is made of: a changed source invalidates the cache
 bool source_hash(const std::string& dir, uint64_t* h) {
-    const char* files[] = {"rt_jit_tu.hip", "rt_trace.hpp", "rt_device.hpp", "rt_types.hpp", "rt_math.hpp", "../../include/rtpbr.h"};
+    const char* files[] = {"rt_jit_tu.hip", "rt_trace.hpp", "rt_persistent.hpp", "rt_device.hpp", "rt_types.hpp", "rt_math.hpp", "../../include/rtpbr.h"};
     uint64_t x = 1469598103934665603ull;
     std::vector<char> buf;
     for (const char* f : files) {
