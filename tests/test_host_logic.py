@@ -331,3 +331,18 @@ def test_run_time_cache_is_bounded(tmp_path, monkeypatch):
     assert f(0, 2, 0x32, 0x9, 1, 5, buf, 512) == 0, lib.rtpbr_last_error()
     left = sorted(os.listdir(tmp_path))
     assert len(left) == 2 and os.path.basename(buf.value.decode()) in left and "old2.hsaco" in left
+
+
+def test_c_abi_header_and_c_host_example_compile_as_plain_c(tmp_path):
+    """include/rtpbr.h is the drop-in boundary: it must be usable from plain C (what cgo / JNI / a C host see).  The header
+    and examples/c_host.c — the Cornell Box rendered through the C ABI without Python — compile as strict C99 and link
+    against the library (no GPU needed to link; tests/test_gpu_examples.py runs it)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(_capi.HIP_LIB_PATH)
+    exe = str(tmp_path / "c_host")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I" + os.path.join(root, "include"),
+                        os.path.join(root, "examples", "c_host.c"), "-L" + lib_dir, "-lrtpbr_hip", "-Wl,-rpath," + lib_dir, "-lm", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.getsize(exe) > 8000
