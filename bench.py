@@ -43,7 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (v_fma_f32 wave64 = 2 cycles on SIMD-32); ubench ceiling 103
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (v_fma_f32 wave64 = 2 cycles on SIMD-32)
+VALU_UBENCH_TFLOPS = 103.0     # tools/ubench/valu_rate.hip on this chip: a pure v_fma_f32 stream issues every 2.45 cycles at the ~1.95 GHz it sustains
 
 
 def parse():
@@ -379,7 +380,9 @@ def main():
                          "primary_rays_avg_launch_ms": round(m["primary_ms"] / max(m["primary_launches"], 1), 3),
                          "primary_rays_launches_timed": m["primary_launches"],
                          "algorithmic_flop_per_unit": round(fpu),
-                         "note": "branchy scalar FP32 on the vector ALU; peak = 157.3 TFLOP/s FP32 vector"
+                         "ubench_ceiling": VALU_UBENCH_TFLOPS, "frac_of_ubench_ceiling": round(tflops / VALU_UBENCH_TFLOPS, 4),
+                         "note": "branchy scalar FP32 on the vector ALU; peak = 157.3 TFLOP/s FP32 vector (spec); ubench_ceiling = what a pure "
+                                 "v_fma_f32 stream sustains on this chip (tools/ubench/valu_rate.hip), reported beside it, never instead of it"
                                  + (" (the neural SDF's f32 MFMA has the same peak rate and does not overlap with VALU work)" if wl.family == "bunny" else "")},
             # the view the metric's name asks for: HBM GB/s of the dominant kernel vs 8 TB/s
             "hbm": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
