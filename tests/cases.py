@@ -68,6 +68,11 @@ def all_cases():
                   env=_env(), env_exposure=1.8, env_gamma=2.2))
     c.append(Case("bunny_chrome_frame30", bunny(aspect=48 / 27, chrome=True),
                   Config.bunny_sdf(48, 27, 10, 8, frame=30), 2, env=_env(), env_exposure=1.8, env_gamma=2.2))
+    # the per-frame animation WITH its vertical bob (bunny_sdf_glass.py:216, bunny_sdf_v2.py:216: p.z += 0.1 sin t; frame != 0)
+    c.append(Case("bunny_glass_frame17", bunny(aspect=48 / 27), Config.bunny_glass(48, 27, 12, 8, frame=17).copy(max_raymarch=512), 2,
+                  env=_env(), env_exposure=1.8, env_gamma=2.2))
+    c.append(Case("bunny_chrome_v2_frame45", bunny(aspect=48 / 27, chrome=True, v2=True),
+                  Config.bunny_sdf(48, 27, 13, 8, frame=45, v2=True), 2, env=_env(), env_exposure=1.8, env_gamma=2.2))
     return c
 
 
