@@ -343,10 +343,10 @@ def test_refresh_semantics():
 
 
 def test_staging_allocation_failure_falls_back_to_fewer_samples_per_launch():
-    """When the device cannot hold the staging of a whole call (one float4 per pixel-sample), the call must split itself
+    """When the device cannot hold the staging of a whole call (one 12-byte record per pixel-sample), the call must split itself
     into smaller launches instead of failing — same bits."""
     import torch
-    W, H, SPP = 1920, 1080, 64                                  # 64 spp: 2.1 GB of staging + 1.1 GB of primary records
+    W, H, SPP = 1920, 1080, 64                                  # 64 spp: 1.6 GB of staging + 1.1 GB of primary records
     sc, cfg = cornell_box("v3", aspect=W / H), Config.cornell_v3(W, H, 0, 8)
     ref = Renderer(sc, cfg)
     ref.sample(SPP)
