@@ -331,9 +331,18 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
  * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes", "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
- * than the 128 it can hold; a power of two, default 16), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
- * "sparse_lanes" (same kernel: the object loop is culled per wave with exact Lipschitz bounds while at most this many
- * lanes march, 0 = never; default 24),
+ * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
+ * "src_track" (same kernel: 1 = tracked-object march steps — a lane that knows a lower bound of every object but the
+ * nearest one evaluates only that one, exactly; heavy waves always use them), "sparse_lanes" (... other waves while at
+ * most this many lanes march, 0 = never; default 24), "leave_x8" (cost of a shading pass in eighths of a march iteration:
+ * the march loop is left when the lane-iterations wasted by finished lanes and parked contexts reach it; default 24),
+ * "src_plan" (1: the pool kernel records every pixel's march steps and re-orders its ownership by them — heaviest pixels
+ * first, the very heaviest in waves of their own), "plan_interval" (bounce-steps on record before a re-plan, default 64),
+ * "heavy_mean_x16" / "heavy_bulk_x16" (a pixel is heavy when its cost exceeds both that many sixteenths of the mean pixel
+ * and of a wave's share of the frame in march iterations; defaults 48, 8), "heavy_own" (pixels per heavy wave, <= 128,
+ * default 80), "tiny_own" / "tiny_waves" (the very heaviest pixels: waves of at most tiny_own pixels, tiny_waves of them —
+ * a quarter of the grid when the launch is as long as its longest chain), "heavy_prio" (heavy waves raise their issue
+ * priority),
  * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
  * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
  * (default), 2 always), "specialize" (1: use the instance compiled

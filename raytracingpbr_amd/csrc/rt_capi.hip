@@ -82,6 +82,9 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->bunny);
     (void)hipFree(c->stage);
     (void)hipFree(c->primary);
+    (void)hipFree(c->cost_buffer);
+    (void)hipFree(c->order);
+    (void)hipFree(c->plan);
     rt_rccl_release(c);
     rt_jit_release(c->jit_mod);
     c->jit_mod = nullptr;
@@ -115,6 +118,10 @@ static void update_tiles(rtpbr_ctx* c) {
     int ntiles = P.ntx * P.nty;
     P.n_local_tiles = (ntiles + c->world - 1) / c->world;
     P.np = P.n_local_tiles * tw * th;
+    // the src/ pool kernel's cost-ordered ownership lists LOCAL pixels: a new partition starts without a plan
+    c->order_valid = false;
+    c->cost_steps = 0;
+    c->plan_np = 0;
 }
 
 // Work items (padded local pixels x samples per launch) are 32-bit: a rank's padded pixel count must
@@ -323,6 +330,88 @@ extern "C" int rtpbr_test_signature(const rtpbr_object* objs, int n, int scale10
         pack_table(objm, n, *sig, packed);
         memcpy(table, packed, 128 * sizeof(float));
     }
+    return RTPBR_OK;
+}
+
+// The key of the run-time instance of a scene (rt_jit.hip): everything the generated code depends on.  P carries the
+// launch constants that get baked (box thresholds, tile geometry, scheduler thresholds, culling decision).
+static void box_thresholds(float rho, int lazy_sqrt, Params& P) {
+    P.box_lazy = (lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
+    // the squared-distance keys of nearest_boxes_lazy are carried scaled by 4 (exact): thresholds likewise
+    P.box_four_rho = 4.0f * rho;
+    P.box_rho2m = (float)((double)rho * (double)rho * (1.0 + 1.0 / 524288.0));
+    if (P.box_rho2m > 0.0f) P.box_rho2m = nextafterf(P.box_rho2m, INFINITY);
+    P.box_4rho2m = nextafterf((float)(4.0 * (double)rho * (double)rho * (1.0 + 1.0 / 524288.0)), INFINITY);
+    P.box_rho2m *= 4.0f;
+    P.box_4rho2m *= 4.0f;
+}
+static RtJitKey make_jit_key(int kind, int n_obj, const ObjM* objm, const rtpbr_config& cfg, const Params& P, bool persistent, int jit_bake,
+                             int jit_waves, bool jit_bunny) {
+    RtJitKey key{};
+    key.kind = kind;
+    key.n_obj = n_obj;
+    for (int i = 0; i < n_obj; i++) {
+        key.types |= (unsigned long long)(objm[i].type + 1) << (4 * i);
+        key.sig |= (unsigned)rotation_class(objm[i].m) << (3 * i);
+    }
+    key.cull = P.cull_ok;
+    key.form = persistent ? 1 : 0;
+    if (jit_bunny) key.sig = 0;
+    key.waves = kind == KIND_BOXES ? 6 : kind == KIND_BUNNY ? 4 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
+    if (jit_waves > 0) key.waves = jit_waves;
+    key.baked = jit_bake;
+    key.table = reinterpret_cast<const unsigned*>(objm);
+    if (key.baked) {
+        rtpbr_config b = cfg;
+        b.seed = 0;
+        b.frame = 0;
+        memcpy(key.cfg_words, &b, sizeof b);
+        key.extra[0] = (unsigned)P.box_lazy;
+        memcpy(&key.extra[1], &P.box_four_rho, 4);
+        memcpy(&key.extra[2], &P.box_rho2m, 4);
+        memcpy(&key.extra[3], &P.box_4rho2m, 4);
+        const int ints[7] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes};
+        memcpy(key.ints, ints, sizeof ints);
+    }
+    return key;
+}
+
+// Test / tooling hook, HOST ONLY (no device needed): compile the BAKED run-time instance of a scene + configuration the
+// way rtpbr_sample() would (single rank, default scheduler thresholds) and return the code object's path, so that the
+// generated ISA can be inspected in a container without a GPU (tools/jit_offline.py).
+extern "C" int rtpbr_test_jit_build_baked(const rtpbr_object* objs, int n, int scale10, const rtpbr_config* cfg, int waves, char* path_out, size_t cap) {
+    if (!objs || !cfg || n <= 0 || n > 8) return fail(RTPBR_EINVAL, "bad arguments");
+    ObjM objm[MAX_OBJ];
+    memset(objm, 0, sizeof objm);
+    bool all_box = true;
+    for (int i = 0; i < n; i++) {
+        rtpbr_transform t = objs[i].transform;
+        if (scale10)
+            for (int k = 0; k < 3; k++) {
+                t.position[k] *= 10.0f;
+                t.scale[k] *= 10.0f;
+            }
+        float rad[3] = {t.rotation[0] * DEG2RAD, t.rotation[1] * DEG2RAD, t.rotation[2] * DEG2RAD};
+        rotate(rad, t.matrix);
+        ObjM& m = objm[i];
+        m.px = t.position[0]; m.py = t.position[1]; m.pz = t.position[2];
+        memcpy(m.m, t.matrix, sizeof m.m);
+        m.sx = t.scale[0]; m.sy = t.scale[1]; m.sz = t.scale[2];
+        m.type = objs[i].type;
+        if (m.type != RTPBR_SHAPE_BOX) all_box = false;
+        if (m.type == RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "analytic shapes only");
+    }
+    rtpbr_ctx defaults;
+    Params P{};
+    P.cfg = *cfg;
+    P.cull_ok = 1;
+    P.tile_w = cfg->width, P.tile_h = cfg->height, P.ntx = 1, P.nty = 1, P.world = 1;
+    P.shade_lanes = defaults.shade_lanes, P.swap_lanes = defaults.swap_lanes;
+    box_thresholds(cfg->box_round, 1, P);
+    const RtJitKey key = make_jit_key(all_box ? KIND_BOXES : KIND_GENERIC, n, objm, *cfg, P, cfg->kernel_form == RTPBR_FORM_PERSISTENT_RAY, 1, waves, false);
+    std::string p;
+    if (int r = rt_jit_build(key, &p, nullptr)) return r;
+    if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());
     return RTPBR_OK;
 }
 
@@ -539,17 +628,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.cull_ok = ok ? 1 : 0;
         P.cull_extent = 4.0f * ext;
     }
-    {
-        const float rho = c->cfg.box_round;
-        P.box_lazy = (c->lazy_sqrt && rho >= 0.0f && rho <= 1e15f) ? 1 : 0;
-        // the squared-distance keys of nearest_boxes_lazy are carried scaled by 4 (exact): thresholds likewise
-        P.box_four_rho = 4.0f * rho;
-        P.box_rho2m = (float)((double)rho * (double)rho * (1.0 + 1.0 / 524288.0));
-        if (P.box_rho2m > 0.0f) P.box_rho2m = nextafterf(P.box_rho2m, INFINITY);
-        P.box_4rho2m = nextafterf((float)(4.0 * (double)rho * (double)rho * (1.0 + 1.0 / 524288.0)), INFINITY);
-        P.box_rho2m *= 4.0f;
-        P.box_4rho2m *= 4.0f;
-    }
+    box_thresholds(c->cfg.box_round, c->lazy_sqrt, P);
     // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
     rt_jit_release(c->jit_mod);
     c->jit_mod = nullptr;
@@ -558,32 +637,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (c->jit != 0 && (persistent || P.scheduler == 1) && c->n_obj <= 8 && (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || (jit_bunny && !persistent))) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
         if (c->jit >= 1 || !aot_special) {
-            RtJitKey key{};
-            key.kind = c->kind;
-            key.n_obj = c->n_obj;
-            for (int i = 0; i < c->n_obj; i++) {
-                key.types |= (unsigned long long)(c->objm[i].type + 1) << (4 * i);
-                key.sig |= (unsigned)rotation_class(c->objm[i].m) << (3 * i);
-            }
-            key.cull = P.cull_ok;
-            key.form = persistent ? 1 : 0;
-            if (jit_bunny) key.sig = 0;
-            key.waves = c->kind == KIND_BOXES ? 6 : c->kind == KIND_BUNNY ? 4 : 5;      // as the ahead-of-time instances (RT_POOL_WAVES*)
-            if (c->jit_waves > 0) key.waves = c->jit_waves;
-            key.baked = c->jit_bake;
-            key.table = reinterpret_cast<const unsigned*>(c->objm);
-            if (key.baked) {
-                rtpbr_config b = c->cfg;
-                b.seed = 0;
-                b.frame = 0;
-                memcpy(key.cfg_words, &b, sizeof b);
-                key.extra[0] = (unsigned)P.box_lazy;
-                memcpy(&key.extra[1], &P.box_four_rho, 4);
-                memcpy(&key.extra[2], &P.box_rho2m, 4);
-                memcpy(&key.extra[3], &P.box_4rho2m, 4);
-                const int ints[7] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes};
-                memcpy(key.ints, ints, sizeof ints);
-            }
+            const RtJitKey key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny);
             RtJitModule* jm = nullptr;
             const int r = rt_jit_acquire(c, key, &jm);
             if (r == RTPBR_OK) {
@@ -646,6 +700,44 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 if (grid < 1) grid = 1;
                 P.total_items = (uint32_t)P.np;
                 P.chunk = (uint32_t)c->residency;                               // bounce-steps per residency (a power of two)
+                // Cost-ordered ownership: the kernel records every pixel's march steps; once plan_interval bounce-steps
+                // are on record the pixels are re-ordered by them (three small kernels on the same stream) and the
+                // heaviest get waves of their own.  The plan survives refresh(): what a pixel costs is a property of
+                // the scene and the camera, not of the accumulated image.
+                P.cost_buffer = nullptr;
+                P.order = nullptr;
+                P.plan = nullptr;
+                P.heavy_own = c->heavy_own;
+                P.heavy_prio = c->heavy_prio;
+                P.src_track = c->src_track;
+                P.leave_x8 = c->leave_x8;
+                P.tiny_own = c->tiny_own;
+                if (c->src_plan) {
+                    if (c->plan_np != (size_t)P.np) {
+                        HIP_TRY(hipStreamSynchronize(c->stream));
+                        (void)hipFree(c->cost_buffer);
+                        (void)hipFree(c->order);
+                        c->cost_buffer = c->order = nullptr;
+                        c->plan_np = 0;
+                        c->order_valid = false;
+                        c->cost_steps = 0;
+                        HIP_TRY(hipMalloc(&c->cost_buffer, (size_t)P.np * sizeof(uint32_t)));
+                        HIP_TRY(hipMalloc(&c->order, (size_t)P.np * sizeof(uint32_t)));
+                        if (!c->plan) HIP_TRY(hipMalloc(&c->plan, sizeof(PlanBuf)));
+                        HIP_TRY(hipMemsetAsync(c->cost_buffer, 0, (size_t)P.np * sizeof(uint32_t), c->stream));
+                        c->plan_np = (size_t)P.np;
+                    }
+                    if (c->cost_steps >= c->plan_interval) {
+                        launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
+                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, c->stream);
+                        c->order_valid = true;
+                        c->cost_steps = 0;
+                    }
+                    P.cost_buffer = c->cost_buffer;
+                    P.order = c->order_valid ? c->order : nullptr;
+                    P.plan = c->plan;
+                    c->cost_steps += steps;
+                }
                 if (c->jit_mod) {
                     if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
                 } else
@@ -856,7 +948,31 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     else if (!strcmp(name, "deposits")) *out = h.deposits + c->deposits_host;
     else if (!strcmp(name, "mlp_wave_evals")) *out = h.mlp_wave_evals;
     else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
-    else if (!strncmp(name, "dbg", 3) && name[3] >= '0' && name[3] <= '7' && !name[4]) *out = h.dbg[name[3] - '0'];
+    else if (!strncmp(name, "dbg", 3) && name[3] >= '0' && name[3] <= '9' && !name[4]) *out = h.dbg[name[3] - '0'];
+    else if (!strncmp(name, "dbg", 3) && name[3] >= 'a' && name[3] <= 'v' && !name[4]) *out = h.dbg[10 + name[3] - 'a'];
+    else if (!strncmp(name, "plan_ge:", 8)) {
+        // pixels whose recorded cost was at least <n> march steps when the current plan was made (whole buckets)
+        *out = 0;
+        if (c->plan && c->order_valid) {
+            const unsigned long long thr = strtoull(name + 8, nullptr, 10);
+            PlanBuf pb;
+            HIP_TRY(hipMemcpy(&pb, c->plan, sizeof pb, hipMemcpyDeviceToHost));
+            for (unsigned b = 1; b < 256; b++) {
+                const unsigned e = (b - 1u) >> 3, m = (b - 1u) & 7u;
+                const unsigned long long fl = e >= 3u ? (unsigned long long)(8u + m) << (e - 3u) : (8u + m) >> (3u - e);
+                if (fl >= thr) *out += pb.hist[b];
+            }
+        }
+    }
+    else if (!strcmp(name, "plan_heavy") || !strcmp(name, "plan_total")) {
+        // the src/ pool kernel's current plan: pixels walked by heavy waves / march steps on record when it was made
+        *out = 0;
+        if (c->plan && c->order_valid) {
+            PlanBuf pb;
+            HIP_TRY(hipMemcpy(&pb, c->plan, sizeof pb, hipMemcpyDeviceToHost));
+            *out = name[5] == 'h' ? pb.n_heavy : pb.total;
+        }
+    }
     else if (!strcmp(name, "jit_active")) *out = c->jit_mod ? 1 : 0;      // the last sample() ran a run-time compiled instance
     else return fail(RTPBR_EINVAL, "unknown counter %s", name);
     return RTPBR_OK;
@@ -925,6 +1041,40 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "sparse_lanes")) {
         if (value < 0 || value > 64) return fail(RTPBR_EINVAL, "sparse_lanes must be 0 (never) .. 64");
         c->sparse_lanes = (int)value;
+    } else if (!strcmp(key, "src_plan")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "src_plan must be 0 or 1");
+        c->src_plan = (int)value;
+        c->order_valid = false;
+        c->cost_steps = 0;
+    } else if (!strcmp(key, "plan_interval")) {
+        if (value < 1 || value > (1 << 20)) return fail(RTPBR_EINVAL, "plan_interval must be 1 .. 2^20 bounce-steps");
+        c->plan_interval = (int)value;
+    } else if (!strcmp(key, "heavy_own")) {
+        if (value < 0 || value > 128) return fail(RTPBR_EINVAL, "heavy_own must be 0 (no heavy waves) .. 128");
+        c->heavy_own = (int)value;
+        c->order_valid = false;       // the plan's share of heavy pixels was sized for the old value
+        c->cost_steps = 0;
+    } else if (!strcmp(key, "src_track")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "src_track must be 0 or 1");
+        c->src_track = (int)value;
+    } else if (!strcmp(key, "tiny_waves")) {
+        if (value < 0 || value > 65535) return fail(RTPBR_EINVAL, "tiny_waves must be 0 .. 65535");
+        c->tiny_waves = (int)value;
+    } else if (!strcmp(key, "tiny_own")) {
+        if (value < 0 || value > 128) return fail(RTPBR_EINVAL, "tiny_own must be 0 (no small heavy waves) .. 128");
+        c->tiny_own = (int)value;
+    } else if (!strcmp(key, "leave_x8")) {
+        if (value < 1 || value > 4096) return fail(RTPBR_EINVAL, "leave_x8 must be 1 .. 4096 (eighths of a march iteration)");
+        c->leave_x8 = (int)value;
+    } else if (!strcmp(key, "heavy_prio")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "heavy_prio must be 0 or 1");
+        c->heavy_prio = (int)value;
+    } else if (!strcmp(key, "heavy_mean_x16")) {
+        if (value < 0 || value > (1 << 20)) return fail(RTPBR_EINVAL, "heavy_mean_x16 must be 0 .. 2^20");
+        c->heavy_mean_x16 = (int)value;
+    } else if (!strcmp(key, "heavy_bulk_x16")) {
+        if (value < 0 || value > (1 << 20)) return fail(RTPBR_EINVAL, "heavy_bulk_x16 must be 0 .. 2^20");
+        c->heavy_bulk_x16 = (int)value;
     } else if (!strcmp(key, "grid_blocks")) {
         if (value < 0 || value > 65535) return fail(RTPBR_EINVAL, "grid_blocks must be 0 (automatic) .. 65535");
         c->grid_blocks = (int)value;

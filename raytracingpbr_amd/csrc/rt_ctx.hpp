@@ -24,6 +24,8 @@ void launch_math_probe(int op, const float* a, const float* b, float* out, float
 int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
+void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
+                 int tiny_waves, int n_cu, hipStream_t st);
 }  // namespace rt
 
 // run-time compiled per-scene instances (rt_jit.hip)
@@ -112,8 +114,25 @@ struct rtpbr_ctx {
     int ready_low = 4;
     int jit_waves = 0;            // waves per SIMD the run-time pool kernel is compiled for (0 = as the ahead-of-time instances)
     int chunk = 0;                // work items claimed per atomic by the pool kernels (0 = automatic)
-    int residency = 16;           // src/ form, pool scheduler: bounce-steps a pixel stays resident when a wave owns more pixels than it holds
-    int sparse_lanes = 24;        // src/ form, pool scheduler: wave-culled object loop when at most this many lanes march
+    int residency = 32;           // src/ form, pool scheduler: bounce-steps a pixel stays resident when a wave owns more pixels than it holds
+    int sparse_lanes = 24;        // src/ form, pool scheduler: tracked-object march steps when at most this many lanes march (heavy waves: always)
+    // src/ form, pool scheduler: cost-ordered ownership (rt_persistent.hpp, plan kernels in rt_kernels.hip)
+    int src_plan = 1;             // 1 = re-plan the ownership from the measured per-pixel cost
+    int plan_interval = 64;       // ... once at least this many bounce-steps have been recorded since the last plan
+    int heavy_own = 80;           // pixels per heavy wave (<= 128)
+    int tiny_waves = 64;          // small heavy waves for the very heaviest pixels (a quarter of the grid when the launch is chain-bound)
+    int tiny_own = 8;             // pixels per small heavy wave (2 or 4 when the budget allows)
+    int leave_x8 = 24;            // a shading pass costs the marching lanes about 3 march iterations
+    int src_track = 1;            // tracked-object march steps (heavy waves, sparse phases) enabled
+    int heavy_prio = 1;           // heavy waves run at raised issue priority
+    int heavy_mean_x16 = 48;      // a pixel is heavy when its cost exceeds 3 x the mean pixel ...
+    int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)
+    uint32_t* cost_buffer = nullptr;   // np x u32
+    uint32_t* order = nullptr;         // np x u32
+    rt::PlanBuf* plan = nullptr;
+    size_t plan_np = 0;                // pixels the three buffers are sized for
+    bool order_valid = false;
+    long long cost_steps = 0;          // bounce-steps recorded in cost_buffer since the last plan
     int grid_blocks = 0;          // src/ form, pool scheduler: workgroups to launch (0 = automatic); tuning / test knob
     int swap_lanes = 8;
     int mlp_lanes = 24;

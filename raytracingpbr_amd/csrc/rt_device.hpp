@@ -539,6 +539,73 @@ RT_D void nearest_exact(const Params& P, vec3 p, int& idx, float& best) {
     }
 }
 
+// ---------------------------------------------------------------- F8 nearest for the tracked-object march (rt_persistent.hpp)
+// nearest_exact that also returns the SECOND smallest |sdf_i| (3e38 when there is no second object): what a lane needs
+// to know to skip every object but the nearest one on its next steps.  best <= second always, so the two smallest of
+// {best, second, d} are min(best, d) and med3(best, second, d): one v_med3 per object on top of nearest_exact.
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void nearest_exact2(const Params& P, vec3 p, int& idx, float& best, float& second) {
+    const int n = NOBJ > 0 ? NOBJ : P.n_obj;
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    idx = 0;
+    second = 3.0e38f;
+    // the reference starts from (0, MAX_DIS) (src/scene.py:46, nearest_init) or from object 0: an initial best of
+    // 3e38 that the first object always beats gives the second form
+    best = P.cfg.nearest_init ? P.cfg.max_dis : 3.0e38f;
+    bool first = !P.cfg.nearest_init;
+    auto visit = [&](float d, int i) {
+        second = __builtin_amdgcn_fmed3f(best, second, d);
+        bool lt = first || d < best;
+        best = lt ? d : best;
+        idx = lt ? i : idx;
+        first = false;
+    };
+    if constexpr (NOBJ > 0) {
+        static_for<NOBJ, 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const ObjM oa = load_obj<SIG, i>(tab);
+            const ObjM ob = load_obj<SIG, (i + 1 < NOBJ ? i + 1 : i)>(tab);
+            if (SIG != 0 || i < P.n_obj) visit(fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i), jit_type(i))), i);
+            if constexpr (i + 1 < NOBJ) {
+                if (SIG != 0 || i + 1 < P.n_obj) visit(fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1), jit_type(i + 1))), i + 1);
+            }
+        });
+    } else {
+        for (int i = 0; i < n; i++) {
+            const ObjM o = tab[i];
+            visit(fabs_(signed_distance<KIND>(P, o, p)), i);
+        }
+    }
+    // (nearest_init: the initial MAX_DIS took part in the med3 as `best`; an object at >= MAX_DIS never wins, and a
+    // `second` of MAX_DIS in place of a larger distance only makes the tracked steps re-evaluate earlier)
+}
+
+// |sdf| of ONE object chosen by a wave-uniform index (scalar compare-and-branch chain over the unrolled table)
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D float sdf_object(const Params& P, int kw, vec3 p) {
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    float r = 0.0f;
+    if constexpr (NOBJ > 0) {
+        static_for<NOBJ, 1>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (kw == i) {
+                // (the empty asm pins the evaluation inside its branch: with a baked table nothing else keeps the compiler
+                // from evaluating all objects speculatively ahead of the chain)
+                vec3 q = p;
+                asm volatile("" : "+v"(q.x));
+                const ObjM o = load_obj<SIG, i>(tab);
+                r = fabs_(signed_distance<KIND>(P, o, q, RT_SIG_CLS(i), jit_type(i)));
+            }
+        });
+    } else {
+        const ObjM o = tab[kw];
+        r = fabs_(signed_distance<KIND>(P, o, p));
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------- F8 nearest with wave-level culling
 // For COHERENT waves (the 64 lanes march almost the same ray: consecutive samples of one pixel)
 // most objects are far from every lane, and exact bounds prove it without evaluating them.

@@ -152,6 +152,110 @@ __global__ void sqrt_exhaustive(unsigned long long* mismatches) {
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// -------------------------------------------------------------------------------------------
+// Cost-ordered ownership of the src/ pool kernel (rt_persistent.hpp): a counting sort of the local pixels by the march
+// steps they took since the last plan (log-scale buckets, 8 per octave; heaviest bucket first; the order inside a bucket
+// is whatever the atomics give — it steers the schedule only, results do not depend on who owns a pixel), and the choice
+// of the pixels that get waves of their own.
+RT_D uint32_t cost_bucket(uint32_t c) {
+    if (c == 0u) return 0u;
+    const int e = 31 - __builtin_clz(c);
+    const uint32_t m = e >= 3 ? (c >> (e - 3)) & 7u : (c << (3 - e)) & 7u;
+    const uint32_t b = (uint32_t)e * 8u + m + 1u;
+    return b < 255u ? b : 255u;
+}
+// smallest cost that falls into bucket b (b >= 1)
+RT_D uint32_t bucket_floor(uint32_t b) {
+    const uint32_t e = (b - 1u) >> 3, m = (b - 1u) & 7u;
+    return e >= 3u ? (8u + m) << (e - 3u) : (8u + m) >> (3u - e);
+}
+__global__ void __launch_bounds__(256) plan_hist(const uint32_t* __restrict__ cost, uint32_t np, PlanBuf* plan) {
+    __shared__ uint32_t h[256];
+    __shared__ unsigned long long tot;
+    h[threadIdx.x] = 0;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (uint32_t q = blockIdx.x * 256u + threadIdx.x; q < np; q += gridDim.x * 256u) {
+        const uint32_t c = cost[q];
+        mine += c;
+        atomicAdd(&h[cost_bucket(c)], 1u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&tot, mine);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&plan->hist[threadIdx.x], h[threadIdx.x]);
+    if (threadIdx.x == 0 && tot) atomicAdd(&plan->total, tot);
+}
+// one block: where every bucket starts in `order` (heaviest first) and how many pixels the heavy waves take.
+// A pixel is heavy when its own chain of march steps is long against BOTH the frame's mean pixel (mean_x16 / 16 times)
+// and a wave's share of the whole frame in march iterations, total / (64 lanes x waves) (bulk_x16 / 16 times).
+__global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uint32_t n_waves, uint32_t heavy_own, uint32_t mean_x16, uint32_t bulk_x16,
+                                                 uint32_t tiny_waves) {
+    __shared__ uint32_t h[256];
+    const uint32_t b = threadIdx.x;
+    h[b] = plan->hist[b];
+    __syncthreads();
+    uint32_t above = 0;                                  // pixels in heavier buckets
+    for (uint32_t j = b + 1u; j < 256u; j++) above += h[j];
+    plan->cursor[b] = above;
+    if (b == 0) {
+        const double total = (double)plan->total;
+        const double t_mean = total / (double)(np ? np : 1u) * (double)mean_x16 / 16.0;
+        const double t_bulk = total / (64.0 * (double)(n_waves ? n_waves : 1u)) * (double)bulk_x16 / 16.0;
+        const double thr = t_mean > t_bulk ? t_mean : t_bulk;
+        uint32_t n_heavy = 0;
+        if (heavy_own > 0u && total > 0.0)
+            for (uint32_t j = 255u; j >= 1u; j--) {
+                if ((double)bucket_floor(j) <= thr) break;
+                n_heavy += h[j];
+            }
+        const unsigned long long cap = (unsigned long long)heavy_own * (unsigned long long)(n_waves / 4u);
+        if (n_heavy > cap) n_heavy = (uint32_t)cap;
+        plan->n_heavy = n_heavy;
+        // Small heavy waves (2..8 pixels: a context never waits for a lane, the lean tracked loop runs most of the time) cost
+        // wave slots.  When the longest chain is several times a wave's share of the frame the launch is as long as that
+        // chain and most of the chip idles anyway (small frames): up to a quarter of the waves; otherwise `tiny_waves`.
+        uint32_t top = 255u;
+        while (top > 0u && h[top] == 0u) top--;
+        const double chain = top ? (double)bucket_floor(top) : 0.0;
+        const double bulk = total / (64.0 * (double)(n_waves ? n_waves : 1u));
+        plan->tiny_waves = chain > 3.0 * bulk ? n_waves / 4u : (tiny_waves < n_waves / 8u ? tiny_waves : n_waves / 8u);
+    }
+}
+// order[cursor[bucket]++] = q, one global atomic per (block, bucket); consumes the costs
+__global__ void __launch_bounds__(256) plan_scatter(uint32_t* __restrict__ cost, uint32_t np, PlanBuf* plan, uint32_t* __restrict__ order) {
+    __shared__ uint32_t cnt[256], base[256];
+    for (uint32_t q0 = blockIdx.x * 256u; q0 < np; q0 += gridDim.x * 256u) {
+        cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t q = q0 + threadIdx.x;
+        uint32_t b = 0, slot = 0;
+        if (q < np) {
+            b = cost_bucket(cost[q]);
+            cost[q] = 0;
+            slot = atomicAdd(&cnt[b], 1u);
+        }
+        __syncthreads();
+        if (cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&plan->cursor[threadIdx.x], cnt[threadIdx.x]);
+        __syncthreads();
+        if (q < np) order[base[b] + slot] = q;
+        __syncthreads();
+    }
+}
+void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
+                 int tiny_waves, int n_cu, hipStream_t st) {
+    (void)hipMemsetAsync(plan, 0, sizeof(PlanBuf), st);
+    long long need = ((long long)np + 255) / 256, grid = (long long)n_cu * 8;
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(plan_hist, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan);
+    hipLaunchKernelGGL(plan_scan, dim3(1), dim3(256), 0, st, plan, np, n_waves, (uint32_t)heavy_own, (uint32_t)mean_x16, (uint32_t)bulk_x16,
+                       (uint32_t)tiny_waves);
+    hipLaunchKernelGGL(plan_scatter, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan, order);
+}
+
 // ---- launchers used by rt_capi.hip -------------------------------------------------------
 #define RT_DISPATCH_SIG(sig, KERNEL, ...) \
         else if (kind == KIND_BOXES && P.n_obj == 8 && P.box_sig == sig) { auto k = KERNEL<KIND_BOXES, 8, sig>; __VA_ARGS__; }

@@ -135,83 +135,181 @@ RT_D void persistent_steps_impl(const Params& P, int steps) {
 //     reaches the bound).  Same wave, same CU: the write-back is visible to the later read without any fence.
 // A pixel is advanced by ONE context at a time and its steps run in order, so its deposits into image_buffer happen
 // in step order (bit-exact with the sequential form) under every ownership / residency choice.
-enum { G_OX = 0, G_OY, G_OZ, G_DX, G_DY, G_DZ, G_CR, G_CG, G_CB, G_DEPTH, G_IDX, G_K, G_S, G_KEY, G_CNT, G_COUNT };
+enum { G_OX = 0, G_OY, G_OZ, G_DX, G_DY, G_DZ, G_CR, G_CG, G_CB, G_DEPTH, G_META, G_K, G_Q, G_KEY, G_CNT, G_COUNT };
 static_assert(G_COUNT == POOL_WORDS, "pixel-context record must fill the pool record");
+// G_META: nearest-object index (5 bits) | bounce-step of this launch the context is at (9 bits: <= 256 steps per kernel) |
+// march steps the context has taken since it was loaded (18 bits, wraps: it only steers the NEXT launch's schedule)
+RT_D uint32_t gmeta_pack(int idx, int s, uint32_t cost) { return (uint32_t)idx | ((uint32_t)s << 5) | (cost << 14); }
+RT_D int gmeta_idx(uint32_t m) { return (int)(m & 31u); }
+RT_D int gmeta_s(uint32_t m) { return (int)((m >> 5) & 511u); }
+RT_D uint32_t gmeta_cost(uint32_t m) { return m >> 14; }
 
 struct PixCtx {
     vec3 o, d, col;
     int depth, idx;
-    uint32_t k;        // the owner wave's k-th pixel: q = wave + k * n_waves
+    uint32_t k;        // the owner wave's k-th pixel
+    uint32_t q;        // local pixel (pixel_of)
     int s;             // bounce-step of this launch the context is at
+    uint32_t cost;     // march steps since the context was loaded
     uint32_t key, cnt;
 };
 
-// wave-uniform constants of the ownership / residency scheme
+// Wave-uniform constants of the ownership / residency scheme.  A wave owns the pixels order[base + k * stride], k < n_own
+// (order = identity when there is no plan yet).  Cost-ordered ownership (round 4): `order` lists the local pixels by the
+// march steps they took over the last launches, heaviest first (plan kernels, rt_kernels.hip).  The first n_heavy of
+// them — pixels whose own dependency chain is comparable with a whole wave's share of the frame: the horizon of the
+// ground sphere, camera rays of 200-512 steps each, 256 times per launch — are dealt in CONTIGUOUS runs of heavy_own to
+// the first waves ("heavy waves": rays of similar length march together, keep all their pixels resident and run the
+// tracked-object march below); the rest is dealt round-robin to the other waves, so every light wave gets the same cost
+// profile and, because the order is kept, starts its own heaviest pixels first in every pass.
 struct SrcWave {
-    uint32_t g, nw;        // this wave, resident waves
+    uint32_t base, stride; // this wave's pixels in `order`
     uint32_t n_own;        // pixels owned
     uint32_t n_items;      // n_own * passes
     uint32_t s_mask;       // residency length - 1 (a power of two), ~0u when the wave keeps its pixels for the whole launch
     int lg_s;              // log2(residency length); 31 when single-pass (s >> 31 == 0)
 };
+RT_D uint32_t own_pixel(const Params& P, const SrcWave& Wv, uint32_t k) {
+    const uint32_t i = Wv.base + k * Wv.stride;
+    return P.order ? P.order[i] : i;
+}
 
-// one iteration of raycast() src/scene.py:59-84 (the ray origin itself moves)
-template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
-RT_D void march_step_src(const Params& P, Lane& L) {
-    float ld = L.dist;
-    int idx;
-    float dist;
-    nearest<KIND, NOBJ, SIG>(P, L.o, idx, dist);
+// one iteration of raycast() src/scene.py:59-84 after nearest() (the ray origin itself moves); returns the step length
+RT_D float march_update_src(const Params& P, Lane& L, int idx, float dist) {
+    // (bitwise on purpose, as in march_update: `&&` / `||` would be lowered to divergent branches with exec-mask
+    // juggling — two dozen scalar instructions in a loop whose length in instructions is what matters)
+    const float ld = L.dist;
     L.idx = idx;
     L.dist = dist;
     L.n_steps++;
     L.steps_left--;
-    bool fb = (L.w > 1.0f) && (ld + dist < L.s);
-    float s_fb = L.s - L.w * L.s;
-    float s_nm = L.w * dist;
-    float s_new = fb ? s_fb : s_nm;
+    const bool fb = (L.w > 1.0f) & (ld + dist < L.s);
+    const float s_fb = L.s - L.w * L.s;
+    const float s_nm = L.w * dist;
+    const float s_new = fb ? s_fb : s_nm;
     L.w = fb ? 1.0f : L.w;
     L.s = s_new;
     L.t += s_new;
     L.o = fma3(s_new, L.d, L.o);
-    bool hit = !fb && (dist < L.t * P.cfg.hit_eps);
-    bool done = (!fb && (hit || L.t >= P.cfg.max_dis)) || L.steps_left == 0;
-    if (done) L.state = hit ? ST_HIT : ST_MISS;
+    const bool nfb = !fb;
+    const bool hit = nfb & (dist < L.t * P.cfg.hit_eps);
+    const bool done = (nfb & (hit | (L.t >= P.cfg.max_dis))) | (L.steps_left == 0);
+    L.state = done ? (hit ? ST_HIT : ST_MISS) : L.state;
+    return s_new;
 }
-
-// The same iteration with the object loop culled at wave level (nearest_culled: exact Lipschitz bounds, lb / ub kept by
-// the caller).  Pays when FEW lanes march — a launch ends with every wave marching the handful of pixels whose raycasts
-// graze the ground for hundreds of steps, and those are near ONE object: the other six are skipped for the whole wave.
-template <int KIND, int NOBJ, uint32_t SIG>
-RT_D void march_step_src_culled(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ > 0 ? NOBJ : 1], uint32_t* dbg_evaluated = nullptr) {
-    const bool active = L.state == ST_MARCH;
-    float ld = L.dist;
+template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
+RT_D void march_step_src(const Params& P, Lane& L) {
     int idx;
     float dist;
-    nearest_culled<KIND, NOBJ, SIG>(P, L.o, L.t, active, ub, lb, idx, dist, dbg_evaluated);
-    float moved = 0.0f;
-    if (active) {
-        L.idx = idx;
-        L.dist = dist;
-        L.n_steps++;
-        L.steps_left--;
-        bool fb = (L.w > 1.0f) && (ld + dist < L.s);
-        float s_fb = L.s - L.w * L.s;
-        float s_nm = L.w * dist;
-        float s_new = fb ? s_fb : s_nm;
-        L.w = fb ? 1.0f : L.w;
-        L.s = s_new;
-        L.t += s_new;
-        L.o = fma3(s_new, L.d, L.o);
-        bool hit = !fb && (dist < L.t * P.cfg.hit_eps);
-        bool done = (!fb && (hit || L.t >= P.cfg.max_dis)) || L.steps_left == 0;
-        if (done) L.state = hit ? ST_HIT : ST_MISS;
-        // the next evaluation point is |s_new| * |d| away; |d| <= 1 + 2^-20
-        moved = fabs_(s_new) * 1.000001f;
-        ub = dist + moved;
+    nearest<KIND, NOBJ, SIG>(P, L.o, idx, dist);
+    march_update_src(P, L, idx, dist);
+}
+
+// ---- tracked-object march (round 4).  Sphere tracing is a dependency chain, and the launch of the fused src/ kernel is
+// as long as the longest chain of ONE pixel (73 206 sequential steps at 1080p, ~230 dependent instructions
+// each).  Those chains belong to rays that graze ONE object for hundreds of steps, so for them the other objects can be
+// skipped — exactly.  |sdf_j| is 1-Lipschitz: after a FULL evaluation at p0 (distances d_j, nearest k, second smallest
+// d2) every other object satisfies, at a later position p,
+//     computed |sdf_j|(p) >= |sdf_j|(p) - eps >= |sdf_j|(p0) - |p - p0| - eps >= d2 - 2 eps - (path marched since),
+// eps = the rounding of one computed distance.  The lane keeps lb = d2 - eps - (marched) - (rounding of the positions and
+// of lb itself); while lb > |sdf_k|(p) + eps, object k is STRICTLY the nearest and (k, |sdf_k|(p)) is bit for bit what
+// nearest() returns.  When the test fails the lane waits (no step is taken, nothing is counted) for the wave's next
+// full evaluation.  eps = 2^-19 (|p|_1 + cull_extent): 16 ulps of everything that enters a distance (positions reach
+// MAX_DIS after an escape, so |p| is taken from the ray, not from the scene).
+// One VGPR of state per lane (lb; <= 0 = "needs a full evaluation"); the tracked object is L.idx.
+RT_D float track_eps(const Params& P, vec3 o) {
+    return 1.9073486328125e-06f * (((fabs_(o.x) + fabs_(o.y)) + fabs_(o.z)) + P.cull_extent);
+}
+// after a step of length s: the next position is |s| |d| away (|d| <= 1 + 2^-20); a quarter of eps covers the rounding
+// of the three coordinates (<= ulp(|p|) = eps / 16) and of the two roundings in this update (<= eps / 32 each)
+RT_D float track_decay(float lb, float s_new, float eps) { return fma_(fabs_(s_new), -1.000001f, lb) - 0.25f * eps; }
+
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void march_step_src_full2(const Params& P, Lane& L, float& lb) {
+    const float eps = track_eps(P, L.o);
+    int idx;
+    float dist, second;
+    nearest_exact2<KIND, NOBJ, SIG>(P, L.o, idx, dist, second);
+    const float s_new = march_update_src(P, L, idx, dist);
+    lb = track_decay(second - eps, s_new, eps);
+}
+// `can`: marching lanes whose lb is valid.  Lanes track different objects: one round per distinct object (grazing rays
+// share theirs), each a wave-uniform jump into that object's unrolled code.
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void march_step_src_tracked(const Params& P, Lane& L, float& lb, bool can, unsigned long long* dbg_rounds = nullptr) {
+    const float eps = track_eps(P, L.o);
+    float dk = 0.0f;
+    unsigned long long todo = __ballot(can);
+    while (todo) {
+        // (evaluated by every lane, kept by the lanes that track this object: were the call inside `if (L.idx == kw)` the
+        // compiler would substitute the per-lane L.idx for the wave-uniform kw and turn the scalar jump into a
+        // divergent evaluation of ALL objects)
+#ifdef RT_DEBUG_PHASE
+        if (dbg_rounds) (*dbg_rounds)++;
+#endif
+        const int kw = __builtin_amdgcn_readlane(L.idx, (int)__builtin_ctzll(todo));
+        const float v = sdf_object<KIND, NOBJ, SIG>(P, kw, L.o);
+        const bool mine = can && L.idx == kw;
+        dk = mine ? v : dk;
+        todo &= ~__ballot(mine);
     }
-#pragma unroll
-    for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
+    const bool ok = can & (lb > dk + eps) & (!P.cfg.nearest_init | (dk < P.cfg.max_dis));
+    if (ok) {
+        const float s_new = march_update_src(P, L, L.idx, dk);
+        lb = track_decay(lb, s_new, eps);
+    } else if (can) {
+        lb = -1.0f;
+    }
+}
+
+// The lean loop of the tracked march: EVERY marching lane tracks the same object I and holds a valid bound.  One
+// object evaluation, the bound test, the raycast bookkeeping and ONE vote per step — a third of the instructions of
+// the general tracked iteration (no per-object rounds, no policy).  A lone wave issues an instruction every ~6 cycles
+// whatever it is, so the length of the critical pixel's chain in time is (steps) x (instructions per iteration) x 6
+// cycles: this loop is what shortens it.  Runs until a lane fails its bound (it then waits for the wave's next full
+// evaluation, lb <= 0), a lane finishes its raycast, or max_it steps were taken; returns the steps taken.
+template <int KIND, int NOBJ, uint32_t SIG, int I>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
+RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_it) {
+    ObjTab tab = obj_table();
+    const bool marching = L.state == ST_MARCH;
+    int it = 0;
+    for (;;) {
+        asm volatile("" : "+s"(tab));
+        const float eps = track_eps(P, L.o);
+        float dk;
+        if constexpr (I >= 0) {
+            const ObjM o = load_obj<SIG, (I >= 0 ? I : 0)>(tab);
+            dk = fabs_(signed_distance<KIND>(P, o, L.o, RT_SIG_CLS((I >= 0 ? I : 0)), jit_type(I)));
+        } else {
+            const ObjM o = tab[k];
+            dk = fabs_(signed_distance<KIND>(P, o, L.o));
+        }
+        const bool ok = marching & (lb > dk + eps) & (!P.cfg.nearest_init | (dk < P.cfg.max_dis));
+        if (ok) {
+            const float s_new = march_update_src(P, L, k, dk);
+            lb = track_decay(lb, s_new, eps);
+        }
+        it++;
+        const bool stop = marching & (!ok | (L.state != ST_MARCH));
+        if (__any(stop) | (it >= max_it)) {
+            if (marching & !ok) lb = -1.0f;
+            break;
+        }
+    }
+    return it;
+}
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D int march_fast_src(const Params& P, Lane& L, float& lb, int k, int max_it) {
+    int it = 0;
+    if constexpr (NOBJ > 0) {
+        static_for<NOBJ, 1>([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value;
+            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i>(P, L, lb, i, max_it);
+        });
+    } else {
+        it = march_fast_src_obj<KIND, NOBJ, SIG, -1>(P, L, lb, k, max_it);
+    }
+    return it;
 }
 
 // Advance a context through the part of its step sequence that needs no marching: roulette,
@@ -223,7 +321,7 @@ template <int KIND>
 RT_D bool pix_advance(const Params& P, const SrcWave& Wv, PixCtx& X, int steps, bool fresh, uint32_t& n_samples, uint32_t& n_dep) {
     const rtpbr_config& g = P.cfg;
     int px, py;
-    pixel_of(P, Wv.g + X.k * Wv.nw, px, py);
+    pixel_of(P, X.q, px, py);
     const size_t pi = (size_t)px * g.height + py;
     for (;;) {
         if (!fresh && (((uint32_t)X.s & Wv.s_mask) == 0u || X.s >= steps)) break;
@@ -260,6 +358,8 @@ RT_D bool pix_advance(const Params& P, const SrcWave& Wv, PixCtx& X, int steps, 
     rb.color[0] = X.col.x; rb.color[1] = X.col.y; rb.color[2] = X.col.z;
     rb.depth = X.depth;
     P.ray_buffer[pi] = rb;
+    // what this residency cost (one context per pixel at a time: a plain read-modify-write; the plan kernels consume and clear it)
+    if (P.cost_buffer) P.cost_buffer[X.q] += X.cost;
     return false;
 }
 
@@ -287,12 +387,58 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
     sstate[lane] = SL_EMPTY;
 
-    // ---- what this wave owns and how it walks it (all wave-uniform)
+    // ---- what this wave owns and how it walks it (all wave-uniform).  Heavy waves first: wave 0 of every block, then
+    // wave 1, ... so that they spread over the CUs (a block's four waves sit on the four SIMDs of one CU)
     SrcWave Wv;
-    Wv.g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wave));
-    Wv.nw = gridDim.x * 4u;
+    const uint32_t nw = gridDim.x * 4u;
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * gridDim.x + blockIdx.x));
     const uint32_t np = (uint32_t)P.np;
-    Wv.n_own = np > Wv.g ? (np - Wv.g - 1u) / Wv.nw + 1u : 0u;
+    // Heavy waves come in two sizes: the very heaviest pixels — the launch's critical path IS one of their chains — sit in
+    // small waves (2 .. tiny_own pixels), where a context never waits for a lane and the lean tracked loop runs most of
+    // the time; the other heavy pixels in waves of heavy_own.
+    uint32_t n_heavy = 0, n_hw = 0, n_top = 0, n_tw = 0;
+    const uint32_t hown = (uint32_t)P.heavy_own;
+    uint32_t town = (uint32_t)P.tiny_own;
+    if (P.order && hown > 0u) {
+        n_heavy = P.plan->n_heavy;
+        n_heavy = n_heavy < np ? n_heavy : np;
+        const uint32_t budget = P.plan->tiny_waves;
+        if (town > 0u && budget > 0u) {
+            // the heaviest pixels in small waves, as small as the plan's budget of waves allows
+            if (n_heavy <= 2u * budget) town = town < 2u ? town : 2u, n_top = n_heavy;
+            else if (n_heavy <= 4u * budget) town = town < 4u ? town : 4u, n_top = n_heavy;
+            else n_top = n_heavy < town * budget ? n_heavy : town * budget;
+            n_tw = (n_top + town - 1u) / town;
+        }
+        n_hw = n_tw + (n_heavy - n_top + hown - 1u) / hown;
+        if (n_hw > nw / 2u) {        // too many for this grid: without the small waves, ...
+            n_top = n_tw = 0;
+            n_hw = (n_heavy + hown - 1u) / hown;
+        }
+        if (n_hw > nw / 2u) {        // ... or with none at all (the plan kernel clamps n_heavy for the grid it was made for)
+            n_hw = 0;
+            n_heavy = 0;
+        }
+    }
+    const bool heavy = h < n_hw;
+    // a heavy wave is the launch's critical path: it issues ahead of the light waves on its SIMD
+    if (heavy && P.heavy_prio > 0) __builtin_amdgcn_s_setprio((short)3);
+    if (h < n_tw) {
+        Wv.base = h * town;
+        Wv.stride = 1u;
+        const uint32_t left = n_top - Wv.base;
+        Wv.n_own = left < town ? left : town;
+    } else if (heavy) {
+        Wv.base = n_top + (h - n_tw) * hown;
+        Wv.stride = 1u;
+        const uint32_t left = n_heavy - Wv.base;
+        Wv.n_own = left < hown ? left : hown;
+    } else {
+        const uint32_t l = h - n_hw, n_lw = nw - n_hw, n_light = np - n_heavy;
+        Wv.base = n_heavy + l;
+        Wv.stride = n_lw;
+        Wv.n_own = n_light > l ? (n_light - l - 1u) / n_lw + 1u : 0u;
+    }
     const uint32_t S = P.chunk;                                   // residency length when the wave owns more than it can hold
     const bool multi = Wv.n_own > 128u && S < (uint32_t)steps;
     Wv.s_mask = multi ? S - 1u : 0xffffffffu;
@@ -309,14 +455,19 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
     L.idx = 0;
     L.steps_left = 0;
-    // bookkeeping of the context being marched
+    // bookkeeping of the context being marched (a_meta: bounce-step and cost as in G_META, index bits zero; the cost is
+    // kept RELATIVE to L.n_steps while the lane marches: subtracted at take-over, added back when the context is parked)
     vec3 a_col = mk(0, 0, 0);
-    int a_depth = 0, a_s = 0;
-    uint32_t a_k = 0, a_key = 0, a_cnt = 0;
+    int a_depth = 0;
+    uint32_t a_k = 0, a_q = 0, a_meta = 0, a_key = 0, a_cnt = 0;
     uint32_t n_samples = 0, n_dep = 0;
     unsigned long long m_ready = 0, m_shade = 0;
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
+    // tracked-object march: lower bound of every object but L.idx (<= 0: needs a full evaluation)
+    float trk_lb = -1.0f;
+    constexpr bool TRK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
+    const bool trk_ok = TRK && P.cull_ok != 0 && P.src_track != 0;
 
     auto f2u = [](float x) { return __builtin_bit_cast(uint32_t, x); };
     auto u2f = [](uint32_t x) { return __builtin_bit_cast(float, x); };
@@ -331,8 +482,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     };
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
-    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_sparse_iters = 0;
-    uint32_t dbg_evaluated = 0;     // objects evaluated by the culled steps (wave level)
+    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
 #endif
 
     for (;;) {
@@ -345,9 +495,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             // not inside the pass, so that a wave whose hand-out is blocked by a straggler learns when it has finished)
             if (multi && safe_until < Wv.n_items && next_item + 64u > safe_until) {
                 uint32_t mine = 0xffffffffu;
-                if (L.state != ST_IDLE) mine = ((uint32_t)a_s >> Wv.lg_s) * Wv.n_own + a_k;
+                if (L.state != ST_IDLE) mine = ((uint32_t)gmeta_s(a_meta) >> Wv.lg_s) * Wv.n_own + a_k;
                 if (sstate[lane] != SL_EMPTY) {
-                    const uint32_t it = (pool[G_S][lane] >> Wv.lg_s) * Wv.n_own + pool[G_K][lane];
+                    const uint32_t it = ((uint32_t)gmeta_s(pool[G_META][lane]) >> Wv.lg_s) * Wv.n_own + pool[G_K][lane];
                     mine = it < mine ? it : mine;
                 }
                 uint32_t low = wave_min_u32(mine);
@@ -365,16 +515,19 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                 PixCtx X;
                 X.o = X.d = X.col = mk(0, 0, 0);
                 X.depth = X.idx = X.s = 0;
-                X.k = X.key = X.cnt = 0;
+                X.k = X.q = X.cost = X.key = X.cnt = 0;
                 bool have = false, fresh = false;
                 if (st == SL_HIT || st == SL_MISS) {
                     X.o = mk(u2f(pool[G_OX][lane]), u2f(pool[G_OY][lane]), u2f(pool[G_OZ][lane]));
                     X.d = mk(u2f(pool[G_DX][lane]), u2f(pool[G_DY][lane]), u2f(pool[G_DZ][lane]));
                     X.col = mk(u2f(pool[G_CR][lane]), u2f(pool[G_CG][lane]), u2f(pool[G_CB][lane]));
                     X.depth = (int)pool[G_DEPTH][lane];
-                    X.idx = (int)pool[G_IDX][lane];
+                    const uint32_t meta = pool[G_META][lane];
+                    X.idx = gmeta_idx(meta);
+                    X.s = gmeta_s(meta);
+                    X.cost = gmeta_cost(meta);
                     X.k = pool[G_K][lane];
-                    X.s = (int)pool[G_S][lane];
+                    X.q = pool[G_Q][lane];
                     X.key = pool[G_KEY][lane];
                     X.cnt = pool[G_CNT][lane];
                     // raytrace() src/pathtracer.py:16-36 after raycast(); depth += 1 (scene.py:83)
@@ -411,8 +564,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                         const uint32_t item = next_item + rank;
                         const uint32_t pass = multi ? item / Wv.n_own : 0u;
                         const uint32_t k = item - pass * Wv.n_own;
+                        const uint32_t q = own_pixel(P, Wv, k);
                         int px, py;
-                        if (pixel_of(P, Wv.g + k * Wv.nw, px, py)) {
+                        if (q < np && pixel_of(P, q, px, py)) {
                             const size_t pi = (size_t)px * P.cfg.height + py;
                             bool masked = P.cfg.adaptive_sampling && !(P.diff_pixels[pi] > P.cfg.noise_threshold);
                             if (!masked) {
@@ -422,7 +576,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                                 X.col = mk(rb.color[0], rb.color[1], rb.color[2]);
                                 X.depth = rb.depth;
                                 X.k = k;
+                                X.q = q;
                                 X.s = (int)(pass << Wv.lg_s);
+                                X.cost = 0;
                                 have = true;
                                 fresh = true;
                             }
@@ -437,8 +593,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     pool[G_DX][lane] = f2u(X.d.x); pool[G_DY][lane] = f2u(X.d.y); pool[G_DZ][lane] = f2u(X.d.z);
                     pool[G_CR][lane] = f2u(X.col.x); pool[G_CG][lane] = f2u(X.col.y); pool[G_CB][lane] = f2u(X.col.z);
                     pool[G_DEPTH][lane] = (uint32_t)X.depth;
+                    pool[G_META][lane] = gmeta_pack(0, X.s, X.cost);
                     pool[G_K][lane] = X.k;
-                    pool[G_S][lane] = (uint32_t)X.s;
+                    pool[G_Q][lane] = X.q;
                     pool[G_KEY][lane] = X.key;
                     pool[G_CNT][lane] = X.cnt;
                     st = SL_READY;
@@ -458,9 +615,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             rec[G_DX] = f2u(L.d.x); rec[G_DY] = f2u(L.d.y); rec[G_DZ] = f2u(L.d.z);
             rec[G_CR] = f2u(a_col.x); rec[G_CG] = f2u(a_col.y); rec[G_CB] = f2u(a_col.z);
             rec[G_DEPTH] = (uint32_t)a_depth;
-            rec[G_IDX] = (uint32_t)L.idx;
+            rec[G_META] = (uint32_t)L.idx | (a_meta + (L.n_steps << 14));
             rec[G_K] = a_k;
-            rec[G_S] = (uint32_t)a_s;
+            rec[G_Q] = a_q;
             rec[G_KEY] = a_key; rec[G_CNT] = a_cnt;
             const int r = pool_swap(V, lane, is_done, L.state == ST_IDLE, L.state == ST_HIT ? SL_HIT : SL_MISS, rec, m_ready, m_shade);
             if (r & 2) L.state = ST_IDLE;
@@ -469,10 +626,12 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                 L.d = mk(u2f(rec[G_DX]), u2f(rec[G_DY]), u2f(rec[G_DZ]));
                 a_col = mk(u2f(rec[G_CR]), u2f(rec[G_CG]), u2f(rec[G_CB]));
                 a_depth = (int)rec[G_DEPTH];
+                a_meta = (rec[G_META] & ~31u) - (L.n_steps << 14);
                 a_k = rec[G_K];
-                a_s = (int)rec[G_S];
+                a_q = rec[G_Q];
                 a_key = rec[G_KEY]; a_cnt = rec[G_CNT];
                 src_march_init(L);
+                trk_lb = -1.0f;
             }
         }
 
@@ -487,35 +646,87 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             }
             const int n_ready = __popcll(m_ready);
             int n_done;
-            bool sparse = false;
-            if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) sparse = P.cull_ok && n_march <= P.sparse_lanes;
-            if (sparse) {
-                if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) {
-                    // few lanes march: cull the object loop for the wave.  The bounds start from "nothing known" (the first
-                    // step evaluates every object, as the plain step does) and live only for this march phase.
-                    float lb[NOBJ];
-#pragma unroll
-                    for (int i = 0; i < NOBJ; i++) lb[i] = -1.0f;
-                    float ub = 3.0e38f;
+            // When to leave the march loop.  Parked READY contexts waiting: as soon as swap_lanes lanes have finished (the
+            // swap is cheap).  None waiting: finished lanes and parked contexts make no progress until the next shading
+            // pass, which stalls the marching lanes for about leave_x8 / 8 march iterations — leave when the lane-iterations
+            // wasted by waiting add up to what leaving costs (ski rental: within 2x of the best fixed batch size for ANY
+            // arrival rate — grazing rays finish once per hundreds of iterations, ordinary ones every twenty).
+            const int n_shade0 = __popcll(m_shade);
+            int waste = 0;
+            bool tracked = false;
+            if constexpr (TRK) tracked = trk_ok && (heavy || n_march <= P.sparse_lanes);
+            if (tracked) {
+                if constexpr (TRK) {
 #ifdef RT_DEBUG_PHASE
                     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
                     do {
+                        // lanes whose bound is valid try the tracked step; the others wait for the wave's next full
+                        // evaluation, which comes when they are more than a quarter of the tracking ones (or nobody tracks)
+                        const bool marching = L.state == ST_MARCH;
+                        const bool can = marching && trk_lb > 0.0f;
+                        const int n_can = __popcll(__ballot(can));
 #ifdef RT_DEBUG_PHASE
                         dbg_march_iters++;
-                        dbg_march_lanes += (unsigned)n_march;
-                        dbg_sparse_iters++;
+                        const uint32_t steps_before = L.n_steps;
+#endif
+                        bool fast = false;
+                        int k0 = 0;
+                        if (n_can == n_march) {      // (n_march > 0 here) do all of them track the same object?
+                            k0 = __builtin_amdgcn_readlane(L.idx, (int)__builtin_ctzll(__ballot(marching)));
+                            fast = __ballot(marching && L.idx != k0) == 0ull;
+                        }
+                        if (fast) {
+                            // the shading pass that waits (if one does) bounds the stay: see the ski-rental rule below
+                            int max_it = 1 << 20;
+                            if (n_ready == 0 && n_shade0 > 0) {
+                                max_it = (P.leave_x8 * n_march - waste * 8 + 8 * n_shade0 - 1) / (8 * n_shade0);
+                                max_it = max_it < 1 ? 1 : max_it;
+                            }
+                            const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it);
+                            if (n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
+#ifdef RT_DEBUG_PHASE
+                            dbg_fast_iters += (unsigned)it;
+#endif
+                        } else if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) {
+#ifdef RT_DEBUG_PHASE
+                            const unsigned long long tt0 = __builtin_readcyclecounter();
+                            march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can, &dbg_trk_rounds);
+                            dbg_t_trk += __builtin_readcyclecounter() - tt0;
+#else
+                            march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can);
 #endif
 #ifdef RT_DEBUG_PHASE
-                        march_step_src_culled<KIND, NOBJ, SIG>(P, L, ub, lb, &dbg_evaluated);
-#else
-                        march_step_src_culled<KIND, NOBJ, SIG>(P, L, ub, lb);
+                            dbg_trk_iters++;
+                            dbg_trk_ok += (unsigned)__popcll(__ballot(L.n_steps != steps_before));
+                            dbg_trk_wait += (unsigned)(n_march - n_can);
+#endif
+                        } else {
+#ifdef RT_DEBUG_PHASE
+                            const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
+                            if (marching) march_step_src_full2<KIND, NOBJ, SIG>(P, L, trk_lb);
+#ifdef RT_DEBUG_PHASE
+                            dbg_t_full2 += __builtin_readcyclecounter() - tt0;
+#endif
+                        }
+#ifdef RT_DEBUG_PHASE
+                        if (!fast && !(n_can > 0 && n_march - n_can < 1 + (n_can >> 2))) dbg_full2_iters++;
+#endif
+#ifdef RT_DEBUG_PHASE
+                        dbg_march_lanes += (unsigned)__popcll(__ballot(L.n_steps != steps_before));
+                        dbg_s_flag += (unsigned)__popcll(__ballot(marching && L.n_steps == steps_before));
+                        dbg_s_done += (unsigned)__popcll(__ballot(!marching && L.state != ST_IDLE));
+                        dbg_s_idle += (unsigned)__popcll(__ballot(L.state == ST_IDLE));
+                        dbg_s_ready += (unsigned)__popcll(m_ready);
+                        dbg_s_shade += (unsigned)__popcll(m_shade);
 #endif
                         n_march = __popcll(__ballot(L.state == ST_MARCH));
                         n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
-                    } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+                        if (n_ready == 0) waste += n_done + n_shade0;
+                    } while (n_march > 0 && (n_ready > 0 ? n_done < m_swap : waste * 8 < P.leave_x8 * n_march));
 #ifdef RT_DEBUG_PHASE
-                    tD += __builtin_readcyclecounter() - ts0;      // (cycles of the sparse march loops, reported in place of the dispatch phase)
+                    tD += __builtin_readcyclecounter() - ts0;      // (cycles of the tracked march loops, reported in place of the dispatch phase)
 #endif
                 }
             } else {
@@ -527,7 +738,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
                     n_march = __popcll(__ballot(L.state == ST_MARCH));
                     n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
-                } while (n_march > 0 && n_done < (n_ready > 0 ? m_swap : 2 * m_swap));
+                    if (n_ready == 0) waste += n_done + n_shade0;
+                } while (n_march > 0 && (n_ready > 0 ? n_done < m_swap : waste * 8 < P.leave_x8 * n_march));
+                trk_lb = -1.0f;     // the plain steps did not maintain the bounds
             }
         }
         RT_PHASE(tA)
@@ -535,13 +748,51 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
     if (lane == 0) {   // cycles per phase and wave lifetime (>> 10), passes, slots shaded, march iterations, lanes marching
         atomicAdd(&P.counters->dbg[0], tB >> 10);
-        atomicAdd(&P.counters->dbg[1], dbg_sparse_iters | ((tD >> 10) << 32));      // march iterations that ran the culled step; their cycles >> 10 in the high word
+        atomicAdd(&P.counters->dbg[1], dbg_trk_iters | ((tD >> 10) << 32));      // march iterations that ran the tracked step; cycles of the tracked loops >> 10 in the high word
         atomicAdd(&P.counters->dbg[2], tA >> 10);
         atomicAdd(&P.counters->dbg[3], (__builtin_readcyclecounter() - t_start) >> 10);
         atomicAdd(&P.counters->dbg[4], dbg_passes);
-        atomicAdd(&P.counters->dbg[5], dbg_shaded | ((unsigned long long)dbg_evaluated << 40));
+        atomicAdd(&P.counters->dbg[5], dbg_shaded);
+        atomicAdd(&P.counters->dbg[14], dbg_trk_ok);
         atomicAdd(&P.counters->dbg[6], dbg_march_iters);
         atomicAdd(&P.counters->dbg[7], dbg_march_lanes);
+        const unsigned long long life = __builtin_readcyclecounter() - t_start;
+        if (heavy) {
+            atomicMax(&P.counters->dbg[8], life);
+            atomicAdd(&P.counters->dbg[9], life >> 10);
+            atomicAdd(&P.counters->dbg[10], 1ull);
+        } else {
+            atomicMax(&P.counters->dbg[11], life);
+        }
+#if RT_DEBUG_PHASE == 2
+        {   // histogram of the wave lifetimes (bins of 16 Mcycles): light waves in dbg[16..31]
+            const unsigned bin = (unsigned)(life >> 24);
+            if (!heavy) atomicAdd(&P.counters->dbg[16 + (bin < 15u ? bin : 15u)], 1ull);
+        }
+        if (false) {
+#else
+        if (heavy && h == 0) {      // the wave that owns the heaviest pixels
+#endif
+            P.counters->dbg[16] = life;
+            P.counters->dbg[17] = tB;
+            P.counters->dbg[18] = tA;
+            P.counters->dbg[19] = dbg_march_iters;
+            P.counters->dbg[20] = dbg_trk_iters;
+            P.counters->dbg[21] = dbg_full2_iters;
+            P.counters->dbg[22] = dbg_passes;
+            P.counters->dbg[23] = dbg_trk_ok;
+            P.counters->dbg[24] = dbg_march_lanes;
+            P.counters->dbg[25] = dbg_trk_rounds;
+            P.counters->dbg[26] = dbg_t_trk;
+            P.counters->dbg[27] = dbg_t_full2;
+            P.counters->dbg[28] = dbg_s_flag;
+            P.counters->dbg[29] = dbg_s_done;
+            P.counters->dbg[30] = dbg_s_idle;
+            P.counters->dbg[31] = dbg_s_ready | (dbg_s_shade << 32);
+        }
+        atomicAdd(&P.counters->dbg[12], dbg_full2_iters);
+        atomicAdd(&P.counters->dbg[13], dbg_trk_wait);
+        atomicAdd(&P.counters->dbg[15], dbg_fast_iters);
     }
 #endif
     flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, n_dep);

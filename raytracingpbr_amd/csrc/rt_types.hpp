@@ -106,8 +106,17 @@ struct Counters {
     unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
     // neural SDF (matrix-core path): MLP passes over a wave, and the ray-evaluations those passes were needed for
     unsigned long long mlp_wave_evals, mlp_lane_evals;
-    // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; "dbg0".."dbg7"
-    unsigned long long dbg[8];
+    // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; "dbg0".."dbgf"
+    unsigned long long dbg[32];
+};
+
+// The plan of the src/ pool kernel's cost-ordered ownership (device memory; written by the plan kernels, rt_kernels.hip)
+struct PlanBuf {
+    uint32_t hist[256];           // pixels per cost bucket (log scale, 8 buckets per octave)
+    uint32_t cursor[256];         // where the next pixel of a bucket goes in `order` (heaviest bucket first)
+    unsigned long long total;     // sum of the costs
+    uint32_t n_heavy;             // the first n_heavy entries of `order` are walked by heavy waves
+    uint32_t tiny_waves;          // how many waves the small heavy waves may take (the kernel sizes them: 2, 4 or tiny_own pixels each)
 };
 
 struct Params {
@@ -130,7 +139,12 @@ struct Params {
     int32_t refill_lanes;   // pool scheduler: start new pixel-samples when this many slots are free (or the pool runs dry)
     int32_t ready_low;      // pool scheduler: also shade when no more than this many READY rays are parked
     int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
-    int32_t sparse_lanes;   // src/ pool kernel: cull the object loop per wave when at most this many lanes march (0 = never)
+    int32_t sparse_lanes;   // src/ pool kernel: tracked-object march steps when at most this many lanes march (0 = only in heavy waves)
+    int32_t heavy_own;      // src/ pool kernel: pixels a heavy wave owns (<= 128: they stay resident for the whole launch)
+    int32_t tiny_own;       // src/ pool kernel: pixels per small heavy wave (the plan says how many such waves there may be)
+    int32_t leave_x8;       // src/ pool kernel: cost of leaving the march loop for a shading pass, in eighths of a march iteration of the wave
+    int32_t src_track;      // src/ pool kernel: 1 = tracked-object march steps enabled
+    int32_t heavy_prio;     // src/ pool kernel: 1 = heavy waves raise their issue priority (s_setprio)
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU
     int32_t mlp_lanes;      // bunny: run the MLP when this many lanes wait for it (or none can run ahead)
@@ -157,6 +171,11 @@ struct Params {
     const float* bunny;     // 625 weights
     unsigned int* work_counter;
     Counters* counters;
+    // src/ pool kernel, cost-ordered ownership (rt_plan.hpp): march steps per local pixel since the last plan (accumulated at
+    // write-back), the local pixels ordered by that cost (heaviest first; nullptr = no plan yet: identity), and the plan
+    uint32_t* cost_buffer;
+    const uint32_t* order;
+    const struct PlanBuf* plan;
     ObjM objm[MAX_OBJ];
 };
 static_assert(sizeof(Params) < 3900, "Params must fit the 4 KB kernarg segment");

@@ -21,7 +21,12 @@ for seed in range(lo, hi):
     if seed % 3 == 0: variants.append({"jit": 1, "jit_bake": seed % 2})      # run-time instance where the scene is eligible
     if cfg.kernel_form == 1:        # src/ form: the pool kernel's ownership / residency / culling choices, the lock-step kernel
         variants += [{"scheduler": 0}, {"grid_blocks": 1, "residency": 2}, {"grid_blocks": 3, "residency": 8, "sparse_lanes": 64, "jit": 1},
-                     {"sparse_lanes": 0, "shade_lanes": 17, "swap_lanes": 5}, {"jit": 1, "jit_bake": 1, "grid_blocks": 2, "residency": 1}]
+                     {"sparse_lanes": 0, "shade_lanes": 17, "swap_lanes": 5}, {"jit": 1, "jit_bake": 1, "grid_blocks": 2, "residency": 1},
+                     # round 4: cost-ordered ownership re-planned after every launch, tracked-object march wherever the scene allows it
+                     {"plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "tiny_own": 2, "jit": 0},
+                     {"plan_interval": 1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "heavy_own": 3, "tiny_waves": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": 1},
+                     {"plan_interval": 2, "heavy_mean_x16": 16, "tiny_own": 4, "tiny_waves": 5, "sparse_lanes": 64, "jit": 1, "leave_x8": 4},
+                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1}]
     for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)

@@ -234,7 +234,19 @@ def test_persistent_form_schedulers_agree():
                         ({"scheduler": 1, "grid_blocks": 9, "residency": 32}, (48,)),
                         ({"scheduler": 1, "grid_blocks": 10, "residency": 4, "shade_lanes": 20}, (48,)),
                         ({"scheduler": 1, "grid_blocks": 3, "residency": 8, "jit": 0}, (30, 18)),
-                        ({"scheduler": 1, "grid_blocks": 64}, (48,))):
+                        ({"scheduler": 1, "grid_blocks": 64}, (48,)),
+                        # cost-ordered ownership (round 4): re-planned from the recorded march steps after the first launch;
+                        # heavy waves of 1 .. 128 pixels, every pixel heavy (thresholds 0: capped at half of the waves), none
+                        # heavy; tracked-object march steps always / never / in sparse phases only
+                        ({"scheduler": 1, "plan_interval": 4}, (5, 43)),
+                        ({"scheduler": 1, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64}, (1, 7, 20, 20)),
+                        ({"scheduler": 1, "plan_interval": 8, "heavy_mean_x16": 16, "heavy_bulk_x16": 0, "heavy_own": 128, "grid_blocks": 6}, (8, 40)),
+                        ({"scheduler": 1, "plan_interval": 8, "heavy_mean_x16": 24, "heavy_bulk_x16": 1, "heavy_own": 1, "sparse_lanes": 0}, (8, 8, 32)),
+                        ({"scheduler": 1, "plan_interval": 2, "heavy_mean_x16": 8, "heavy_own": 33, "grid_blocks": 2, "residency": 4, "jit": 0}, (2, 30, 16)),
+                        ({"scheduler": 1, "plan_interval": 16, "heavy_own": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": 1}, (16, 32)),
+                        ({"scheduler": 1, "plan_interval": 4, "heavy_mean_x16": 20, "heavy_bulk_x16": 0, "tiny_own": 2, "tiny_waves": 7, "leave_x8": 1}, (4, 44)),
+                        ({"scheduler": 1, "plan_interval": 4, "heavy_mean_x16": 20, "heavy_bulk_x16": 0, "tiny_own": 8, "tiny_waves": 3, "leave_x8": 400, "src_track": 0}, (4, 44)),
+                        ({"scheduler": 1, "src_plan": 0, "sparse_lanes": 64}, (48,))):
         r = Renderer(case.scene, case.cfg)
         case.setup(r)
         for k, v in opts.items():
@@ -390,7 +402,8 @@ def test_error_channel():
         r.sample(1)                                      # env-map sky without an env map
     with pytest.raises(RtpbrError):
         r.set_option("no_such_option", 1)
-    for key, value in (("chunk", 8193), ("residency", 12), ("residency", 512), ("sparse_lanes", 65), ("grid_blocks", -1)):
+    for key, value in (("chunk", 8193), ("residency", 12), ("residency", 512), ("sparse_lanes", 65), ("grid_blocks", -1), ("heavy_own", 129), ("plan_interval", 0), ("tiny_own", 129),
+                       ("leave_x8", 0), ("src_plan", 2)):
         with pytest.raises(RtpbrError):                  # out of range (chunk: the 32-bit work counter's overshoot margin)
             r.set_option(key, value)
     with pytest.raises(ValueError):
@@ -567,6 +580,23 @@ def test_fuzz_random_scenes_match_oracle(seed):
     if cfg.kernel_form == 1:
         assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer))
     g.close()
+    if cfg.kernel_form == 1:
+        # the src/ pool kernel's cost-ordered ownership and tracked-object march (round 4) on every kind of scene the fuzzer makes
+        # (cones, planes, rotated shapes, both nearest_init conventions): re-planned after every launch, every pixel with a
+        # recorded cost heavy, waves of 2 / 3 / 80 pixels, tracked steps whenever the scene allows them — in the ahead-of-time
+        # and in the run-time compiled instance
+        for opts in ({"plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "tiny_own": 2, "jit": 0},
+                     {"plan_interval": 1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "heavy_own": 3, "tiny_waves": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": seed % 2},
+                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1}):
+            g = Renderer(sc, cfg)
+            for k, v in opts.items():
+                g.set_option(k, v)
+            g = run(g, env, n, True)
+            cg = g.counters()
+            assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
+                   (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits), opts
+            assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)) and np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), opts
+            g.close()
 
 
 @pytest.mark.parametrize("seed", range(16))

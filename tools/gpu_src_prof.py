@@ -27,18 +27,30 @@ print(json.dumps({"W": W, "H": H, "scheduler": sched, "steps": steps, "launches"
                   "G_bounce_steps_per_s": round(c.samples / tr / 1e6, 3), "G_march_steps_per_s": round(c.march_steps / tr / 1e6, 2),
                   "raycasts_per_step": round(c.raycasts / c.samples, 4), "march_per_raycast": round(c.march_steps / max(c.raycasts, 1), 3),
                   "hits_per_step": round(c.hits / c.samples, 4), "deposits_per_step": round(c.deposits / c.samples, 4),
-                  "jit": r.counter("jit_active")}), flush=True)
+                  "jit": r.counter("jit_active"), "plan_heavy": r.counter("plan_heavy"), "plan_total": r.counter("plan_total")}), flush=True)
 if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
-    d = [r.counter("dbg%d" % i) for i in range(8)]
+    d = [r.counter("dbg" + "0123456789abcdefghijklmnopqrstuv"[i]) for i in range(32)]
     if sched == 0:
         print(json.dumps({"max_march_steps_of_one_pixel": d[0], "mean_over_waves_of_max_lane": round(d[1] / (W * H / 64), 1),
                           "mean_march_steps_per_pixel": round(c.march_steps / (W * H), 1)}), flush=True)
         raise SystemExit
     waves = max(1, round(W * H / 128 / 4 + 0.5)) * 4
     print(json.dumps({"phase_Mcycles": {"B_and_dispatch": d[0] >> 10, "march": d[2] >> 10, "wave_life_sum": d[3] >> 10},
-                      "passes": d[4], "slots_shaded_per_pass": round((d[5] & ((1 << 40) - 1)) / max(d[4], 1), 2),
-                      "objects_evaluated_per_sparse_iter": round((d[5] >> 40) / max(d[1] & 0xffffffff, 1), 2), "march_iters": d[6], "sparse_iters": d[1] & 0xffffffff, "cycles_per_sparse_iter": round(((d[1] >> 32) << 10) / max(d[1] & 0xffffffff, 1)),
-                      "cycles_per_dense_iter": round(((d[2] - (d[1] >> 32)) << 10) / max(d[6] - (d[1] & 0xffffffff), 1)),
+                      "passes": d[4], "slots_shaded_per_pass": round(d[5] / max(d[4], 1), 2),
+                      "march_iters": d[6], "fast_iters": d[15], "tracked_iters": d[1] & 0xffffffff, "full2_iters": d[12],
+                      "ok_lanes_per_tracked_iter": round(d[14] / max(d[1] & 0xffffffff, 1), 2),
+                      "waiting_lanes_per_tracked_iter": round(d[13] / max(d[1] & 0xffffffff, 1), 2),
+                      "cycles_per_iter_in_tracked_loops": round(((d[1] >> 32) << 10) / max((d[1] & 0xffffffff) + d[12], 1)),
+                      "cycles_per_plain_iter": round(((d[2] - (d[1] >> 32)) << 10) / max(d[6] - (d[1] & 0xffffffff) - d[12], 1)),
+                      "heavy_waves": d[10], "heavy_wave_life_Mcycles_max_mean": [round(d[8] / 1e6, 1), round((d[9] << 10) / max(d[10], 1) / 1e6, 1)],
+                      "light_wave_life_Mcycles_max": round(d[11] / 1e6, 1),
                       "lanes_per_march_iter": round(d[7] / max(d[6], 1), 2),
                       "cycles_per_pass": round((d[0] << 10) / max(d[4], 1)), "cycles_per_march_iter": round((d[2] << 10) / max(d[6], 1))}), flush=True)
+    if 'RT_DEBUG_PHASE=2' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
+        print(json.dumps({'light_wave_life_hist_16Mcycle_bins': d[16:32]}), flush=True)
+    elif sched == 1 and d[16]:
+        print(json.dumps({"wave0": {"life_Mcycles": round(d[16] / 1e6, 1), "B_Mcycles": round(d[17] / 1e6, 1), "march_Mcycles": round(d[18] / 1e6, 1), "march_iters": d[19],
+                                    "tracked_iters": d[20], "full2_iters": d[21], "passes": d[22], "tracked_ok_lanesteps": d[23], "lanesteps": d[24], "tracked_rounds": d[25], "cycles_per_tracked_step": round(d[26] / max(d[20], 1)), "cycles_per_full2_step": round(d[27] / max(d[21], 1)),
+                                    "per_iter": {"stepping": round(d[24] / max(d[19], 1), 1), "flagged_waiting": round(d[28] / max(d[19], 1), 1), "done_waiting": round(d[29] / max(d[19], 1), 1),
+                                                 "idle_lanes": round(d[30] / max(d[19], 1), 1), "parked_ready": round((d[31] & 0xffffffff) / max(d[19], 1), 1), "parked_to_shade": round((d[31] >> 32) / max(d[19], 1), 1)}}}), flush=True)
 r.close()
