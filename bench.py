@@ -143,14 +143,18 @@ def make_renderer(wl, device, a, jit=True, bake=True):
     return r
 
 
-def measure(wl, r, steps, warmup, fence=None, gather=None):
+def measure(wl, r, steps, warmup, fence=None, gather=None, one_step_launches=False):
     """W warm-up + K timed steps of one workload on an already configured renderer; returns the wall time and the per-launch
     figures of the kernels (HIP events recorded on the context's own stream by the library)."""
     form_src = wl.family == "src"
 
     def step():
         r.refresh()
-        r.sample(wl.spp)
+        if one_step_launches:
+            for _ in range(wl.spp):
+                r.sample(1)
+        else:
+            r.sample(wl.spp)
         if gather is not None:
             gather()
 
@@ -165,6 +169,8 @@ def measure(wl, r, steps, warmup, fence=None, gather=None):
         step()
         # HIP-event timing of the kernels; reading it waits for the step, which the timed region must wait for anyway
         tr, _tot, n = r.last_sample_ms()
+        if one_step_launches:        # (the library keeps the events of the last rtpbr_sample() call only: scale the last launch)
+            tr, n = tr * wl.spp, n * wl.spp
         trace_ms += tr
         launches += n
         if not form_src:
@@ -192,9 +198,23 @@ def side_config(name, a, device, rank0_of=1):
     bounded sample count, with its own FLOP model"""
     from raytracingpbr_amd import workloads
     from raytracingpbr_amd.tiles import default_tile
-    bounded = {"c1": 16, "c3": 256, "c4": 256, "c5": 128, "src": 256, "src_4k": 256}[name]
-    wl = workloads.get("src", 3840, 2160, bounded) if name == "src_4k" else workloads.get(name, spp=bounded)
+    fast = name.endswith("_fast")
+    name_ = name[:-5] if fast else name
+    bounded = {"c1": 16, "c2": 256, "c3": 256, "c3_valu": 256, "c4": 256, "c5": 128, "src": 256, "src_4k": 256, "src_768": 256, "src_1step": 256}[name_]
+    base = {"src_4k": "src", "src_768": "src", "src_1step": "src", "c3_valu": "c3"}.get(name_, name_)
+    dims = {"src_4k": (3840, 2160), "src_768": (768, 432)}.get(name_, (0, 0))
+    wl = workloads.get(base, dims[0], dims[1], bounded)
     r = make_renderer(wl, device, a, jit=not a.no_jit)
+    if fast:
+        # the tolerance flavour of the same kernels (option precision = 1: hardware sqrt / rcp / sin / exp, contraction — the
+        # regime the reference itself runs in, Taichi's default fast_math); NOT bit-exact, held to the north star's per-pixel
+        # L2 < 1e-3 against the oracle by tests/test_gpu_fast.py; the headline stays the exact kernels
+        r.set_option("precision", 1)
+    if name == "c3_valu":
+        # north_star: "no MFMA".  The same network on the vector ALU only (scheduler-0 kernel), beside the default instance
+        # whose hidden layers run as f32 MFMA (bit-identical results; same FP32 peak rate): the A/B that backs the choice
+        r.set_option("mlp_mfma", 0)
+    one_step_launches = name_ == "src_1step"      # the way the reference calls it: ONE bounce-step per pathtrace() launch (src/renderer.py:29-30)
     W, H = wl.cfg.width, wl.cfg.height
     share = ""
     if wl.virtual_world > 1:
@@ -205,11 +225,22 @@ def side_config(name, a, device, rank0_of=1):
         r.set_option("reserve_spp", wl.spp)
     r.sample(wl.spp)
     r.sync()
-    steps = 20 if name == "c1" else 2
-    m = measure(wl, r, steps, 1)
+    steps = 20 if name_ == "c1" else 2
+    m = measure(wl, r, steps, 1, one_step_launches=one_step_launches)
     c, fpu, kernel_s, tflops = roofline_of(wl, r, m, steps, W * H)
+    if one_step_launches:       # the counters are those of the LAST launch (one bounce-step per pixel)
+        kernel_s = m["trace_ms"] / 1e3 / steps
+        tflops = fpu * c.samples * wl.spp / max(kernel_s, 1e-9) / 1e12
+        c.samples *= wl.spp
     units = c.samples * steps
-    out = {"workload": wl.title.replace(f"{workloads.get(wl.name).spp} spp", f"{wl.spp} spp") + share,
+    title = wl.title.replace(f"{workloads.get(wl.name).spp} spp", f"{wl.spp} spp") + share
+    if one_step_launches:
+        title = title.replace(f"{wl.spp} launches fused", f"{wl.spp} separate launches of ONE bounce-step each (rtpbr_sample(ctx, 1), as src/renderer.py:29-30 calls pathtrace())")
+    if name == "c3_valu":
+        title += "; option mlp_mfma = 0: the network on the vector ALU only"
+    if fast:
+        title += "; option precision = 1: tolerance flavour (per-pixel L2 < 1e-3 vs the oracle, tests/test_gpu_fast.py), not bit-exact"
+    out = {"workload": title,
            "value": round(units / m["dt"] / 1e6, 1), "unit": wl.unit, "units_per_step": c.samples, "steps": steps,
            "ms_per_step": round(m["dt"] / steps * 1e3, 3), "kernel_ms_per_step": round(kernel_s * 1e3, 3),
            "algorithmic_flop_per_unit": round(fpu), "achieved_tflops": round(tflops, 2), "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
@@ -217,6 +248,9 @@ def side_config(name, a, device, rank0_of=1):
            "run_time_kernels": bool(r.counter("jit_active"))}
     if wl.family == "bunny":
         out["mlp_evaluations_per_unit"] = round(r.counter("mlp_lane_evals") / max(c.samples, 1), 2)
+    if name == "c3_valu":       # the vector-ALU kernel does not count network evaluations: no FLOP model for this entry, compare `value` with c3
+        for k in ("algorithmic_flop_per_unit", "achieved_tflops", "frac", "mlp_evaluations_per_unit"):
+            out[k] = None
     r.close()
     return out
 
@@ -350,6 +384,12 @@ def main():
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
         except Exception:
             pass
+        if wl.family == "src":
+            res = 32        # option "residency": bounce-steps between two T6 round trips of a pixel (multi-pass walk)
+            impl_bytes = int(80 * W * H * max(1, SPP // res) + 32 * c.deposits + 16 * c.sky_lookups)
+        else:
+            split_on = m["primary_launches"] > 0
+            impl_bytes = int((24 + (16 if split_on else 0)) * c.samples + 32 * W * H * (launches / a.steps) + 16 * c.sky_lookups)
         jit_on = bool(r.counter("jit_active"))
         if wl.family == "src":
             kname, pname = ("rt_jit_persistent_pool" if jit_on else "persistent_pool"), None
@@ -390,7 +430,14 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes),
                     "achieved_counters": round(traffic / avg_launch_s / 1e9, 2) if traffic else None,
                     "frac_counters": round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
-                    "traffic": traffic, "kernel": kname},
+                    "traffic": traffic, "kernel": kname,
+                    "traffic_kind": "a COMMITTED constant from the PMC passes of profiles/hbm_traffic.json (rocprofv3 cannot run inside this process), not a measurement of this run" if traffic else None,
+                    # what THIS run moved by construction, from its own counts (per step, all kernels): the complete-path form stages
+                    # 12 B per sample (pool kernel W, accumulate R) and 8 B of primary record per sample (primary kernel W, pool
+                    # kernel R) and read-modify-writes T7 once per pixel and launch; the src/ form moves T6 (40 B R + W) per pixel
+                    # and residency, T7 (16 B R + W) per deposit and 16 B per sky lookup
+                    "implementation_bytes_per_step": impl_bytes, "implementation_gbs": round(impl_bytes / max(dt / a.steps, 1e-9) / 1e9, 2),
+                    "implementation_frac": round(impl_bytes / max(dt / a.steps, 1e-9) / 1e9 / HBM_PEAK_GBS, 5)},
         }
         if wl.family != "src":
             split = m["primary_launches"] > 0
@@ -417,7 +464,8 @@ def main():
                     r2.close()
             out["jit"] = jit
             if a.workload == "c2" and not a.no_configs:
-                out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c4", "c5", "src", "src_4k")}
+                out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c3_valu", "c4", "c5", "src", "src_768", "src_4k", "src_1step",
+                                                                                 "c2_fast", "c3_fast", "c4_fast", "src_fast")}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -346,8 +346,9 @@ static void box_thresholds(float rho, int lazy_sqrt, Params& P) {
     P.box_4rho2m *= 4.0f;
 }
 static RtJitKey make_jit_key(int kind, int n_obj, const ObjM* objm, const rtpbr_config& cfg, const Params& P, bool persistent, int jit_bake,
-                             int jit_waves, bool jit_bunny) {
+                             int jit_waves, bool jit_bunny, int fast = 0) {
     RtJitKey key{};
+    key.fast = fast;
     key.kind = kind;
     key.n_obj = n_obj;
     for (int i = 0; i < n_obj; i++) {
@@ -379,7 +380,7 @@ static RtJitKey make_jit_key(int kind, int n_obj, const ObjM* objm, const rtpbr_
 // Test / tooling hook, HOST ONLY (no device needed): compile the BAKED run-time instance of a scene + configuration the
 // way rtpbr_sample() would (single rank, default scheduler thresholds) and return the code object's path, so that the
 // generated ISA can be inspected in a container without a GPU (tools/jit_offline.py).
-extern "C" int rtpbr_test_jit_build_baked(const rtpbr_object* objs, int n, int scale10, const rtpbr_config* cfg, int waves, char* path_out, size_t cap) {
+extern "C" int rtpbr_test_jit_build_baked(const rtpbr_object* objs, int n, int scale10, const rtpbr_config* cfg, int waves, int fast, char* path_out, size_t cap) {
     if (!objs || !cfg || n <= 0 || n > 8) return fail(RTPBR_EINVAL, "bad arguments");
     ObjM objm[MAX_OBJ];
     memset(objm, 0, sizeof objm);
@@ -408,7 +409,7 @@ extern "C" int rtpbr_test_jit_build_baked(const rtpbr_object* objs, int n, int s
     P.tile_w = cfg->width, P.tile_h = cfg->height, P.ntx = 1, P.nty = 1, P.world = 1;
     P.shade_lanes = defaults.shade_lanes, P.swap_lanes = defaults.swap_lanes;
     box_thresholds(cfg->box_round, 1, P);
-    const RtJitKey key = make_jit_key(all_box ? KIND_BOXES : KIND_GENERIC, n, objm, *cfg, P, cfg->kernel_form == RTPBR_FORM_PERSISTENT_RAY, 1, waves, false);
+    const RtJitKey key = make_jit_key(all_box ? KIND_BOXES : KIND_GENERIC, n, objm, *cfg, P, cfg->kernel_form == RTPBR_FORM_PERSISTENT_RAY, 1, waves, false, fast);
     std::string p;
     if (int r = rt_jit_build(key, &p, nullptr)) return r;
     if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());
@@ -636,8 +637,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     const bool persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
     if (c->jit != 0 && (persistent || P.scheduler == 1) && c->n_obj <= 8 && (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || (jit_bunny && !persistent))) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
-        if (c->jit >= 1 || !aot_special) {
-            const RtJitKey key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny);
+        if (c->jit >= 1 || !aot_special || c->precision) {
+            const RtJitKey key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny, c->precision);
             RtJitModule* jm = nullptr;
             const int r = rt_jit_acquire(c, key, &jm);
             if (r == RTPBR_OK) {
@@ -651,6 +652,10 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         return fail(RTPBR_ESTATE, "option jit = 2 (strict): no run-time instance exists for this scene (needs <= 8 analytic shapes, "
                                   "or the neural shape with jit_bake, and the pool scheduler)");
     }
+    if (c->precision && !c->jit_mod)
+        return fail(RTPBR_ESTATE, "option precision = 1 (the tolerance flavour) exists as a run-time compiled instance only: needs hipcc and the kernel "
+                                  "sources on this machine, option jit != 0, a scene of <= 8 analytic shapes (or the neural shape with jit_bake = 1, jit >= 1) "
+                                  "and the pool scheduler");
     pack_objects(c, P);
     if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
@@ -1098,6 +1103,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
             return fail(RTPBR_EINVAL, "jit must be -1 (when no ahead-of-time specialisation fits), 0 (never), 1 (always, falling back to the "
                                       "ahead-of-time instance if compilation is impossible) or 2 (always, an error otherwise)");
         c->jit = (int)value;
+    } else if (!strcmp(key, "precision")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "precision must be 0 (exactly rounded, the default) or 1 (tolerance flavour: hardware sqrt / rcp / sin / exp, contraction)");
+        c->precision = (int)value;
     } else if (!strcmp(key, "jit_bake")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "jit_bake must be 0 or 1");
         c->jit_bake = (int)value;

@@ -36,6 +36,7 @@ struct RtJitKey {
     int cull, waves;
     int form;                   // 0 = complete-path kernels, 1 = persistent-ray kernels (only those are compiled)
     int baked;                  // 1: the march table and the render configuration are baked into the code object
+    int fast;                   // 1: the tolerance flavour (RT_FAST_MATH, rt_math.hpp): hardware sqrt / rcp / sin / exp, contraction
     const unsigned* table;      // n_obj x 16 words (ObjM blocks)
     unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed
     unsigned extra[4];          // box_lazy, box_four_rho, box_rho2m, box_4rho2m (bit patterns)
@@ -152,6 +153,7 @@ struct rtpbr_ctx {
     // the scene, 0 = never, 1 = always (falling back to the ahead-of-time kernels if it cannot be built), 2 = always, an
     // error otherwise
     int jit = -1;
+    int precision = 0;                // 0 = exactly rounded arithmetic (bit-identical with the oracle), 1 = the tolerance flavour (run-time instances only)
     int jit_bake = 0;                 // 1: run-time instances carry the scene's constants as literals
     RtJitModule* jit_mod = nullptr;   // the one the last rtpbr_sample() used, pinned until the next one (nullptr = ahead-of-time instance)
     unsigned jit_sig = 0;

@@ -464,9 +464,11 @@ RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
         visit(oa, i, RT_SIG_CLS(i));
         if constexpr (i + 1 < NOBJ) visit(ob, i + 1, RT_SIG_CLS(i + 1));
     });
+#if !RT_FAST_MATH      // (tolerance flavour: near-ties go either way; an object in its rounding shell is off by <= rho)
     const float lim = k1 * 1.00000095367431640625f;    // 1 + 2^-20
     const bool suspect = k3 <= lim || (k2 <= lim && (k2 != k1 || has_core)) || (k1 < P.box_rho2m && k2 < P.box_4rho2m);
     if (__any(suspect)) return false;
+#endif
     const bool core = !(pmx > 0.0f);
     float d = core ? rho - pmx : fabs_(sqrt_quarter_(k1) - rho);
     if (P.cfg.nearest_init && !(d < P.cfg.max_dis)) {   // src/ form: the search starts from (0, MAX_DIS)
@@ -707,6 +709,9 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
         // practically every step.  Wave-uniform branch: taken if ANY active lane is in the band.
         // (thresholds t * (eps (1 -+ 2^-20)): a conservative pre-filter, 16 ulp wide against two roundings; any
         // lane inside the band sends the wave to the exact quotient, so the decision is the reference's either way)
+#if RT_FAST_MATH
+        bool hit_n = dist < L.t * P.cfg.hit_eps;      // tolerance flavour: the product decides
+#else
         bool sure_hit = dist < L.t * (P.cfg.hit_eps * 0.99999905f);
         bool sure_miss = dist > L.t * (P.cfg.hit_eps * 1.00000095f);
         bool unsure = !(sure_hit || sure_miss) || !(L.t > 0.0f);
@@ -715,6 +720,7 @@ RT_D void march_update(const Params& P, Lane& L, int idx, float dist) {
             float err = dist / L.t;
             hit_n = err < P.cfg.hit_eps;
         }
+#endif
         float s_nm = L.w * dist;
         float s_new = fb ? s_fb : s_nm;
         L.s = s_new;

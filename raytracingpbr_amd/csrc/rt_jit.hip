@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -238,8 +239,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
             for (char ch : f) th = (th ^ (unsigned char)ch) * 1099511628211ull + 1;
     }
     char name[256];
-    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, key.form, (unsigned long long)th, (unsigned long long)sh);
+    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d%s_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, key.fast ? "_fast" : "", (unsigned long long)th, (unsigned long long)sh);
     const std::string cdir = cache_dir();
     if (cdir.empty())
         return rt_fail(RTPBR_ESTATE, "run-time compilation is off: no cache directory that is owned by this user and closed to others "
@@ -248,13 +249,17 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     {
         std::vector<char> probe;
         if (read_owned_file(path, probe)) {      // a cache hit must pass the same ownership test the loader applies
+            (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);      // pruning is by mtime: make it follow use
             *out = path;
             return RTPBR_OK;
         }
     }
+    static std::atomic<unsigned> g_build_seq{0};
     char tmp[64];
-    snprintf(tmp, sizeof tmp, ".tmp.%d", (int)getpid());
-    // everything this process writes carries its pid: ranks of one job build the same key at the same time
+    snprintf(tmp, sizeof tmp, ".tmp.%d.%u", (int)getpid(), g_build_seq.fetch_add(1u));
+    // everything this build writes carries the pid (ranks of one job build the same key at the same time) and a
+    // process-wide sequence number (two threads of one process building it for two devices: the registry's BUILDING
+    // marker is per device)
     const std::string tpath = path + tmp, log = tpath + ".log";
     std::string table_def;
     const std::string tfile = tpath + ".table.hpp";
@@ -298,6 +303,11 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
                                      "-fno-slp-vectorize", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-Wno-unused-value",
                                      d[0], d[1], d[2], d[3], d[4], d[5], d[6], dir + "/rt_jit_tu.hip", "-o", tpath};
+    if (key.fast) {
+        // the tolerance flavour (rt_math.hpp RT_FAST_MATH): contraction allowed, v_rcp-based divide, hardware transcendentals
+        argv[5] = "-ffp-contract=fast";
+        argv.insert(argv.begin() + 10, {"-DRT_FAST_MATH=1", "-fno-hip-fp32-correctly-rounded-divide-sqrt"});
+    }
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     argv.insert(argv.begin() + 10, extra.begin(), extra.end());
     const int rc = run(argv, log);
@@ -305,10 +315,11 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     const bool have_out = stat(tpath.c_str(), &ost) == 0 && ost.st_size > 0;
     // rc -2: the exit status was lost (SIGCHLD ignored by the host): a complete output file decides
     if (!((rc == 0 || rc == -2) && have_out)) {
+        // hipcc ran and said no: the same call fails the same way next time — unless its input vanished under it
+        const bool table_there = !key.baked || access(tfile.c_str(), R_OK) == 0;
         unlink(tpath.c_str());
         if (key.baked) unlink(tfile.c_str());
-        // hipcc ran and said no (or could not be run at all): the same call fails the same way next time
-        if (deterministic) *deterministic = rc > 0;
+        if (deterministic) *deterministic = rc > 0 && table_there;
         return rt_fail(RTPBR_ESTATE, "run-time compilation failed (hipcc log: %s)", log.c_str());
     }
     (void)chmod(tpath.c_str(), 0600);
@@ -324,14 +335,20 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
 }
 
 static void unload_module(RtJitModule* m) {
-    // kernels of a context that has moved on to another instance may still be in flight
+    // kernels of a context that has moved on to another instance may still be in flight; the caller's current device
+    // is restored (rtpbr_sample goes on to launch on ITS device after rt_jit_acquire)
+    int cur = -1;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     if (hipSetDevice(m->device) == hipSuccess) (void)hipDeviceSynchronize();
     if (m->module) (void)hipModuleUnload(m->module);
+    if (have_cur) (void)hipSetDevice(cur);
     delete m;
 }
 
-// keep at most RTPBR_JIT_MAX_MODULES loaded instances (g_mu held): unload the least recently used unpinned ones
-static void evict_modules() {
+// keep at most RTPBR_JIT_MAX_MODULES loaded instances (g_mu held): take the least recently used unpinned ones out of the
+// registry; the caller unloads them AFTER releasing the lock (a device-wide synchronisation must not stall every other
+// context's acquire / release)
+static void evict_modules(std::vector<RtJitModule*>& victims) {
     long cap = 64;
     if (const char* e = getenv("RTPBR_JIT_MAX_MODULES")) cap = atol(e);
     if (cap < 1) cap = 1;
@@ -344,7 +361,7 @@ static void evict_modules() {
             if (it->second.mod->pins == 0 && (victim == g_modules.end() || it->second.mod->last_use < victim->second.mod->last_use)) victim = it;
         }
         if (n <= cap || victim == g_modules.end()) return;
-        unload_module(victim->second.mod);
+        victims.push_back(victim->second.mod);
         g_modules.erase(victim);
     }
 }
@@ -352,8 +369,8 @@ static void evict_modules() {
 // The instance of `key` on c's device, PINNED (rt_jit_release when the context stops using it).
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     char id[224];
-    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_f%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, key.form, (unsigned long long)baked_hash(key));
+    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_f%d_p%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, key.fast, (unsigned long long)baked_hash(key));
     if (const char* e = getenv("RTPBR_JIT_EXTRA_FLAGS")) snprintf(id + strlen(id), sizeof id - strlen(id), "_x%zx", std::hash<std::string>()(e));
     {
         std::unique_lock<std::mutex> lock(g_mu);
@@ -373,24 +390,39 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
         g_modules[id] = Entry{};                                     // E_BUILDING
     }
     // ---- compile and load WITHOUT the registry lock: other keys, contexts and threads proceed
+    bool settled = false;
     auto settle = [&](RtJitModule* m, bool remember_failure, const char* why) {
-        std::lock_guard<std::mutex> lock(g_mu);
-        if (m) {
-            Entry& e = g_modules[id];
-            e.state = E_READY;
-            e.mod = m;
-            m->pins = 1;
-            m->last_use = ++g_tick;
-            evict_modules();
-        } else if (remember_failure) {
-            Entry& e = g_modules[id];
-            e.state = E_FAILED;
-            e.error = why ? why : "";
-        } else {
-            g_modules.erase(id);                                     // transient: the next call tries again
+        std::vector<RtJitModule*> victims;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            if (m) {
+                Entry& e = g_modules[id];
+                e.state = E_READY;
+                e.mod = m;
+                m->pins = 1;
+                m->last_use = ++g_tick;
+                evict_modules(victims);
+            } else if (remember_failure) {
+                Entry& e = g_modules[id];
+                e.state = E_FAILED;
+                e.error = why ? why : "";
+            } else {
+                g_modules.erase(id);                                 // transient: the next call tries again
+            }
+            settled = true;
+            g_cv.notify_all();
         }
-        g_cv.notify_all();
+        for (RtJitModule* v : victims) unload_module(v);
     };
+    // whatever leaves this function without settling (std::bad_alloc from the string / vector work below) must not leave
+    // the BUILDING marker behind: every later acquire of the key would wait for it forever
+    struct Guard {
+        decltype(settle)& fn;
+        bool& done;
+        ~Guard() {
+            if (!done) fn(nullptr, false, nullptr);
+        }
+    } guard{settle, settled};
     std::string path;
     bool deterministic = false;
     if (int r = rt_jit_build(key, &path, &deterministic)) {

@@ -18,6 +18,22 @@
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_D __device__ __forceinline__
 
+// RT_FAST_MATH = 1 (run-time compiled instances only, option "precision" = 1): the TOLERANCE flavour.  The reference runs
+// under Taichi's default fast-math (src/config.py:5, ti.init without fast_math=False: LLVM reassociation / contraction,
+// approximate sin/cos/pow/rsqrt on GPU backends — SURVEY.md D4), i.e. it never promised more than this: square roots and
+// reciprocal square roots are the hardware approximations with ONE correction step (v_sqrt / v_rsq), the neural SDF's 48
+// sines per evaluation are v_sin_f32, exp / log the hardware v_exp / v_log, products and sums may be
+// contracted (-ffp-contract=fast), f32 divide is v_rcp-based (-fno-hip-fp32-correctly-rounded-divide-sqrt), and the exact
+// decision bands of the march loop are dropped.  Not bit-exact with anything; held to the north star's per-pixel L2 bar
+// against the oracle by tests/test_gpu_fast.py.  The exact flavour (0, default) stays the parity anchor.
+#ifndef RT_FAST_MATH
+#define RT_FAST_MATH 0
+#endif
+#if RT_FAST_MATH && !defined(__HIP_DEVICE_COMPILE__)
+#undef RT_FAST_MATH
+#define RT_FAST_MATH 0          // the host pass only parses the device functions
+#endif
+
 namespace rt {
 
 constexpr float PI = 3.14159274f;
@@ -47,8 +63,23 @@ RT_HD float dot(vec3 a, vec3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x
 // zero/inf handling: 11 instructions instead of ~17.  Valid for 0 <= x < 2^95 (every length
 // on this path; distances are < MAX_DIS = 2000).  tests/test_gpu_parity.py checks it against
 // the compiler's IEEE sqrt for ALL 2^31 non-negative bit patterns below 2^95.
-RT_HD float sqrt_(float x) {
+// tolerance flavour: v_sqrt_f32 (<= 1 ulp) + one residual correction y + (x - y^2) / (2 y): within 0.5 ulp + a few 2^-24
+// of an ulp, i.e. the correctly rounded result for all but about one argument in a thousand, in 6 instructions instead
+// of 11 — a bare v_sqrt_f32 is NOT enough here: |sqrt(s2) - r| cancels against the 100-unit ground sphere of the src /
+// Tokyo scenes, 1 ulp of 100 is 7.6e-6, and hit thresholds are ~1e-4 t (measured: 0.8 % of the samples changed colour)
+RT_HD float sqrt_fast_(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 1.0e-36f));
+    return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+RT_HD float sqrt_(float x) {
+#if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT)
+    return sqrt_fast_(x);
+#elif defined(__HIP_DEVICE_COMPILE__)
     float xs = x * 4294967296.0f;
     float y = __builtin_amdgcn_sqrtf(xs);
     float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
@@ -64,7 +95,9 @@ RT_HD float sqrt_(float x) {
 }
 // sqrt_(x / 4) for an x that is an exact multiple-of-4 scaling: the same v_sqrt_f32 input (x/4 * 2^32 = x * 2^30)
 RT_HD float sqrt_quarter_(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT)
+    return 0.5f * sqrt_fast_(x);
+#elif defined(__HIP_DEVICE_COMPILE__)
     float xs = x * 1073741824.0f;
     float y = __builtin_amdgcn_sqrtf(xs);
     float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
@@ -81,7 +114,14 @@ RT_HD float sqrt_quarter_(float x) {
 RT_HD float sqrt_ieee_(float x) { return __builtin_sqrtf(x); }
 RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
 RT_HD vec3 normalize(vec3 a) {
+#if RT_FAST_MATH
+    // v_rsq_f32 + one Newton step (directions feed positions at t ~ 10: 1 ulp of a direction is 1e-6 of a position)
+    const float s2 = dot(a, a);
+    float inv = __builtin_amdgcn_rsqf(s2);
+    inv = inv * __builtin_fmaf(-0.5f * s2, inv * inv, 1.5f);
+#else
     float inv = 1.0f / sqrt_(dot(a, a));
+#endif
     return a * inv;
 }
 RT_HD vec3 cross(vec3 a, vec3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
@@ -101,6 +141,8 @@ RT_HD vec3 mulv(const float* m, vec3 v) {
 
 // sin/cos: Cody-Waite reduction by pi/2 + Cephes sinf/cosf kernels on [-pi/4, pi/4]
 RT_HD void sincos_(float a, float* s_out, float* c_out) {
+    // (the tolerance flavour keeps this polynomial pair: it runs twice per surface interaction, not in the march loop, and
+    // v_sin_f32 / v_cos_f32 are good to ~1e-6 ABSOLUTE only — as a direction that is 1e-5 of a position ten units away)
     float kf = __builtin_rintf(a * TWO_OVER_PI);
     int k = (int)kf;
     float r = fma_(kf, -1.5703125f, a);
@@ -132,6 +174,9 @@ RT_HD float sin_(float a) {
 // pre-activations reach |k| ~ 100); one odd degree-9 minimax polynomial on [-pi/2, pi/2] (max abs error 1.2e-7); the
 // sign is applied with one v_lshl_add_u32 (parity << 31 ADDED to the bit pattern).  Deterministic for every input.
 RT_HD float sin_pi_(float a) {
+#if RT_FAST_MATH
+    return __builtin_amdgcn_sinf(a * INV_2PI);      // |a| stays below ~100 pi in the network: inside the instruction's +-256 revolutions
+#endif
     const float magic = 12582912.0f;
     float t = fma_(a, INV_PI, magic);
     float kf = t - magic;
@@ -146,6 +191,9 @@ RT_HD float sin_pi_(float a) {
 
 // exp: Cephes expf
 RT_HD float exp_(float x) {
+#if RT_FAST_MATH
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#endif
     float kf = __builtin_rintf(x * 1.44269504088896341f);
     float r = fma_(kf, -0.693359375f, x);
     r = fma_(kf, 2.12194440e-4f, r);
@@ -166,6 +214,9 @@ RT_HD float exp_(float x) {
 // log (Cephes logf) and pow(x, y) = exp(y*log(x)) for x >= 0 (tone map, env preprocess);
 // x < 0 gives NaN like powf.
 RT_HD float log_(float x) {
+#if RT_FAST_MATH
+    return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+#endif
     int e = 0;
     if (x < 1.17549435e-38f) {
         x = x * 16777216.0f;

@@ -1,0 +1,152 @@
+"""The tolerance flavour of the run-time compiled kernels (option precision = 1, rt_math.hpp RT_FAST_MATH) against the
+CPU oracle (run with -m gpu).
+
+The exact kernels are bit-identical with the oracle; this flavour is not and is not meant to be: hardware sqrt / rsq /
+rcp / sin / cos / exp / log, contraction, v_rcp-based divides, no exact decision bands — the regime the reference itself
+runs in (Taichi's default fast_math, src/config.py:5, examples/bunny/bunny_sdf_glass.py:7).  It is held to the north
+star's stated bar instead: display-space per-pixel L2 = sqrt(mean_p |a_p - b_p|^2 / 3) < 1e-3 between
+the HIP frame and the oracle's frame with the IDENTICAL random stream — BASELINE configs[0] (C1) in full, and C2 / C3 / C4
+on sub-frames (a sparse set of tiles) at the config's full sample count, which is as much as the oracle renders in
+seconds.  Where the two differ it is because a sample took a different decision (hit / miss at a grazing ray, reflect /
+refract, roulette): the flip rate — the fraction of samples whose colour differs from the exact kernels' beyond
+rounding — is measured per sample on whole frames and printed.
+"""
+import numpy as np
+import pytest
+
+from oracle_backend import OracleRenderer
+from raytracingpbr_amd import Renderer, workloads
+from raytracingpbr_amd.tiles import TileLayout
+
+pytestmark = pytest.mark.gpu
+L2_BAR = 1e-3          # BASELINE.json north_star: "per-pixel L2 < 1e-3 vs reference"
+
+
+@pytest.fixture(autouse=True)
+def _private_jit_cache(tmp_path, monkeypatch):
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+
+
+def l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def hip(wl, precision, W=0, H=0):
+    r = Renderer(wl.scene, wl.cfg)
+    wl.setup(r)
+    r.set_option("jit", 2)
+    r.set_option("jit_bake", 1)
+    r.set_option("precision", precision)
+    return r
+
+
+def test_precision_needs_a_run_time_instance():
+    from raytracingpbr_amd._capi import RtpbrError
+    wl = workloads.get("c1")
+    r = Renderer(wl.scene, wl.cfg)
+    r.set_option("jit", 0)
+    r.set_option("precision", 1)
+    with pytest.raises(RtpbrError):
+        r.sample(1)
+    with pytest.raises(RtpbrError):
+        r.set_option("precision", 2)
+    r.set_option("precision", 0)
+    r.sample(1)
+    r.close()
+
+
+def test_c1_full_frame_l2():
+    """BASELINE configs[0] complete: Cornell 256x256, 16 spp, 4 bounces."""
+    wl = workloads.get("c1")
+    g = hip(wl, 1)
+    g.render(refreshing=True, spp=wl.spp)
+    assert g.counter("jit_active") == 1
+    o = OracleRenderer(wl.scene, wl.cfg)
+    wl.setup(o)
+    o.render(refreshing=True, spp=wl.spp)
+    d_disp, d_lin = l2(g.image_pixels, o.image_pixels), l2(g.image_buffer[..., :3] / wl.spp, o.image_buffer[..., :3] / wl.spp)
+    differing = float(np.mean(np.any(g.image_pixels != o.image_pixels, axis=-1)))
+    print(f"[fast] c1 full frame: display-space L2 {d_disp:.3e} (linear mean radiance {d_lin:.3e}); pixels that differ at all {differing:.3f}")
+    assert np.all(g.image_buffer[..., 3] == wl.spp) and np.all(np.isfinite(g.image_pixels))
+    assert d_disp < L2_BAR
+    assert differing > 0.0        # it IS a different flavour (a silent fall-back to the exact kernels would give 0)
+    g.close()
+
+
+@pytest.mark.parametrize("name,tile,rank,world", [("c2", 16, 301, 1021), ("c3", 16, 437, 1020), ("c4", 16, 1203, 8100), ("c4", 16, 5, 4050)])
+def test_subframe_at_full_sample_count_l2(name, tile, rank, world):
+    """C2 / C3 / C4 at the config's resolution and FULL sample count on a sparse set of 16x16 tiles (one virtual rank of
+    `world`): 8-9 tiles spread over the frame."""
+    wl = workloads.get(name)
+    W, H = wl.cfg.width, wl.cfg.height
+    own = TileLayout(W, H, tile, tile, world).owner_map() == rank
+    g = hip(wl, 1)
+    g.set_tiles(tile, tile, rank, world)
+    g.sample(wl.spp)
+    g.post_process()
+    o = OracleRenderer(wl.scene, wl.cfg)
+    wl.setup(o)
+    o.set_tiles(tile, tile, rank, world)
+    o.sample(wl.spp)
+    o.post_process()
+    gp, op = g.image_pixels[own], o.image_pixels[own]
+    gl, ol = g.image_buffer[own], o.image_buffer[own]
+    assert np.all(gl[:, 3] == wl.spp) and np.all(np.isfinite(gp))
+    d_disp, d_lin = l2(gp, op), l2(gl[:, :3] / wl.spp, ol[:, :3] / wl.spp)
+    cg, co = g.counters(), o.counters()
+    print(f"[fast] {name} {W}x{H} x {wl.spp} spp on {int(own.sum())} pixels: display-space L2 {d_disp:.3e} (linear {d_lin:.3e}); "
+          f"raycasts {cg.raycasts} vs {co.raycasts}, march steps {cg.march_steps} vs {co.march_steps}")
+    assert d_disp < L2_BAR
+    # the work the two flavours did agrees to a fraction of a percent (decision flips are rare)
+    assert abs(cg.raycasts - co.raycasts) <= 2e-3 * co.raycasts and abs(cg.march_steps - co.march_steps) <= 5e-3 * co.march_steps
+    g.close()
+
+
+def test_src_form_l2():
+    """The src/ persistent-ray pipeline (tracked-object march, cost-ordered ownership and all) in the tolerance flavour:
+    768x432 (the reference's default window, src/config.py:7-8), 512 launches of one bounce-step per pixel."""
+    wl = workloads.get("src", 768, 432)
+    g = hip(wl, 1)
+    g.set_option("plan_interval", 64)
+    o = OracleRenderer(wl.scene, wl.cfg)
+    wl.setup(o)
+    for r in (g, o):
+        r.refresh()
+        r.sample(512)
+        r.post_process()
+    d_disp = l2(g.image_pixels, o.image_pixels)
+    n_g, n_o = g.image_buffer[..., 3], o.image_buffer[..., 3]
+    print(f"[fast] src 768x432 x 512 bounce-steps: display-space L2 {d_disp:.3e}; deposits per pixel {n_g.mean():.2f} vs {n_o.mean():.2f}, "
+          f"pixels whose deposit count differs {float(np.mean(n_g != n_o)):.2e}")
+    assert np.all(np.isfinite(g.image_pixels))
+    assert d_disp < L2_BAR
+    g.close()
+
+
+# (the neural SDF is a fit with |grad| between 0.6 and 1.1 and its normals are finite differences over 1e-4: a sample's path
+# is sensitive to the last bits of the network's output — the reference's own renders differ like this between two machines)
+@pytest.mark.parametrize("name,w,h,n,bar", [("c2", 1920, 1080, 4, 1e-4), ("c4", 960, 540, 4, 5e-3), ("c3", 480, 270, 4, 1e-1)])
+def test_flip_rate_per_sample(name, w, h, n, bar):
+    """Per-sample colours of the two flavours on whole frames (the exact kernels are bit-identical with the oracle, so they
+    stand in for it where the oracle would take minutes): a sample 'flips' when its colour differs beyond rounding."""
+    wl = workloads.get(name, w, h)
+    ge, gf = hip(wl, 0), hip(wl, 1)
+    flips = total = 0
+    worst = 0.0
+    for k in range(n):
+        for r in (ge, gf):
+            r.refresh()
+            r.set_option("sample_base", k)
+            r.sample(1)
+        a, b = ge.image_buffer[..., :3].astype(np.float64), gf.image_buffer[..., :3].astype(np.float64)
+        d = np.abs(a - b).max(axis=-1)
+        tol = 1e-3 * np.maximum(1.0, np.abs(a).max(axis=-1))
+        flips += int((d > tol).sum())
+        total += d.size
+        worst = max(worst, float((d / np.maximum(1.0, np.abs(a).max(axis=-1)))[d <= tol].max(initial=0.0)))
+    rate = flips / total
+    print(f"[fast] {name} {w}x{h}: flip rate {rate:.3e} ({flips} of {total} samples differ by more than 1e-3 relative); "
+          f"largest difference among the others {worst:.2e}")
+    assert rate < bar
+    ge.close(); gf.close()

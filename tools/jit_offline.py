@@ -1,6 +1,6 @@
 """BUILD CONTAINER (no GPU needed): compile the BAKED run-time instance of a workload the way rtpbr_sample() would and
 print the register / scratch / LDS use of its kernels; with --asm also dump the disassembly.
-    python tools/jit_offline.py src [W H] [--waves N] [--asm out.s]
+    python tools/jit_offline.py src [W H] [--waves N] [--fast] [--asm out.s]
 """
 import ctypes as C, os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 name = args[0] if args else "src"
 W, H = (int(args[1]), int(args[2])) if len(args) >= 3 else (0, 0)
 waves = int(sys.argv[sys.argv.index("--waves") + 1]) if "--waves" in sys.argv else 0
+fast = 1 if "--fast" in sys.argv else 0
 wl = workloads.get(name, W, H)
 lib = C.CDLL(HIP_LIB_PATH)
 lib.rtpbr_last_error.restype = C.c_char_p
@@ -21,8 +22,8 @@ n = len(wl.scene.objects)
 arr = (SDFObject * n)(*wl.scene.objects)
 buf = C.create_string_buffer(1024)
 cache = os.environ.setdefault("RTPBR_JIT_CACHE", tempfile.mkdtemp(prefix="rtpbr_jit_"))
-lib.rtpbr_test_jit_build_baked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Config), C.c_int, C.c_char_p, C.c_size_t]
-rc = lib.rtpbr_test_jit_build_baked(arr, n, 1 if wl.scene.scale10 else 0, C.byref(wl.cfg), waves, buf, 1024)
+lib.rtpbr_test_jit_build_baked.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Config), C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+rc = lib.rtpbr_test_jit_build_baked(arr, n, 1 if wl.scene.scale10 else 0, C.byref(wl.cfg), waves, fast, buf, 1024)
 if rc:
     raise SystemExit("build failed: %s" % lib.rtpbr_last_error().decode())
 path = buf.value.decode()
