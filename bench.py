@@ -67,7 +67,9 @@ def parse():
                     help="N > 1 gather: rccl = the library's own ncclGather (default), torch = torch.distributed nccl, host = gloo through host memory")
     ap.add_argument("--backend", default=None, help="(compatibility) nccl = --transport torch, gloo = --transport host")
     ap.add_argument("--collective-at-1", action="store_true", help="with --gpus 1: still set up a (1-rank) RCCL communicator and run the gather every step")
-    ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (with --transport host)")
+    ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (--transport host, or --transport rccl with RTPBR_RCCL_LIB "
+                                                                "pointing at tests/stubs/libfake_rccl.so: RCCL itself refuses two ranks on one device)")
+    ap.add_argument("--check-gather", action="store_true", help="N > 1: rank 0 also renders the frame untiled and reports whether the gathered frame equals it bit for bit")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
     if a.backend == "gloo":
@@ -356,6 +358,17 @@ def main():
         dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms_per_step": round(render_ms / a.steps, 3),
                                           "gather_ms_per_step": round(sum(gather_ms[-a.steps:]) / a.steps, 3), "wall_s": round(m["dt"], 4)})
         multi["per_rank"] = per_rank
+        if a.check_gather and rank == 0:
+            import numpy as np
+            # the same sequence of steps, untiled (sample indices advance from step to step; the src/ form also keeps ray state)
+            full = make_renderer(wl, local_rank, a, jit=not a.no_jit)
+            full.sample(SPP)
+            for _ in range(a.warmup + a.steps):
+                full.refresh()
+                full.sample(SPP)
+            multi["gathered_equals_untiled"] = bool(np.array_equal(np.ascontiguousarray(r.image_buffer).view(np.uint32),
+                                                                   np.ascontiguousarray(full.image_buffer).view(np.uint32)))
+            full.close()
 
     if rank == 0:
         c, fpu, kernel_s, tflops = roofline_of(wl, r, m, a.steps, W * H)

@@ -855,7 +855,8 @@ extern "C" int rtpbr_sync(rtpbr_ctx* c) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (int r = set_dev(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return RTPBR_OK;
+    // a gather enqueued earlier has run by now: what did the communicator make of it (any rank)?
+    return rt_rccl_check_async(c);
 }
 
 static int buf_ptr(rtpbr_ctx* c, int which, void** p, size_t* n) {

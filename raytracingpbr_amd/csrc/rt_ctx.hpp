@@ -166,4 +166,5 @@ struct rtpbr_ctx {
     size_t gather_recv_cap = 0;   // bytes of gather_recv (rank 0: local share x world)
 };
 void rt_rccl_release(rtpbr_ctx* c);
+int rt_rccl_check_async(rtpbr_ctx* c);      // RTPBR_OK when the context has no communicator
 

@@ -32,6 +32,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;           // optional
     decltype(&ncclGather) Gather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -69,6 +70,7 @@ int load_rccl() {
     RT_SYM(CommUserRank, "ncclCommUserRank");
     RT_SYM(GetVersion, "ncclGetVersion");
 #undef RT_SYM
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
     g_rccl.h = h;
     return RTPBR_OK;
 }
@@ -159,6 +161,26 @@ extern "C" int rtpbr_rccl_init_all(rtpbr_ctx** ctxs, int n) {
     return RTPBR_OK;
 }
 
+// What the communicator says about work it has already been given (rccl.h: ncclCommGetAsyncError).  Asked on EVERY rank
+// right after the enqueue (a sender's failure must not be silent: only the root used to ask), and again by rtpbr_sync()
+// once the stream has drained, when the gather has actually run.
+int rt_rccl_check_async(rtpbr_ctx* c) {
+    if (!c || !c->comm || !g_rccl.CommGetAsyncError) return RTPBR_OK;
+    ncclResult_t async = ncclSuccess;
+    NCCL_TRY(g_rccl.CommGetAsyncError((ncclComm_t)c->comm, &async));
+    if (async != ncclSuccess && async != ncclInProgress)
+        return rt_fail(RTPBR_EHIP, "RCCL asynchronous error on this rank: %s", g_rccl.GetErrorString(async));
+    return RTPBR_OK;
+}
+// a communicator whose collective could not be enqueued is unusable (the other ranks may be waiting inside it): abort it
+// so that nothing hangs in a later call, the caller sets up a new one (rtpbr_rccl_init) after handling the error
+static void abort_comm(rtpbr_ctx* c) {
+    if (!c->comm) return;
+    if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c->comm);
+    else (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+}
+
 // pack -> ncclGather -> (root) unpack, all on the context's stream
 static int enqueue_gather(rtpbr_ctx* c) {
     RT_HIP_TRY(hipSetDevice(c->device));
@@ -180,9 +202,6 @@ static int enqueue_unpack(rtpbr_ctx* c) {
         launch_unpack(P, (const float4*)c->gather_recv + (size_t)src * (size_t)c->P.np, c->stream);
     }
     RT_HIP_TRY(hipGetLastError());
-    ncclResult_t async = ncclSuccess;
-    NCCL_TRY(g_rccl.CommGetAsyncError((ncclComm_t)c->comm, &async));
-    if (async != ncclSuccess) return rt_fail(RTPBR_EHIP, "RCCL asynchronous error: %s", g_rccl.GetErrorString(async));
     return RTPBR_OK;
 }
 
@@ -190,8 +209,12 @@ extern "C" int rtpbr_gather_tiles(rtpbr_ctx* c) {
     if (int r = check_comm(c)) return r;
     RT_HIP_TRY(hipSetDevice(c->device));
     if (int r = ensure_gather_buffers(c)) return r;
-    if (int r = enqueue_gather(c)) return r;
-    return enqueue_unpack(c);
+    if (int r = enqueue_gather(c)) {
+        abort_comm(c);
+        return r;
+    }
+    if (int r = enqueue_unpack(c)) return r;
+    return rt_rccl_check_async(c);      // every rank, sender or root
 }
 
 extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
@@ -204,10 +227,18 @@ extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
     NCCL_TRY(g_rccl.GroupStart());
     int rc = RTPBR_OK;
     for (int i = 0; i < n && rc == RTPBR_OK; i++) rc = enqueue_gather(ctxs[i]);
-    NCCL_TRY(g_rccl.GroupEnd());
-    if (rc != RTPBR_OK) return rc;
+    const ncclResult_t ge = g_rccl.GroupEnd();        // the group is always closed, whatever happened inside it
+    if (rc != RTPBR_OK || ge != ncclSuccess) {
+        // a member could not be enqueued (or the group could not be launched): the ranks that were are waiting for it —
+        // abort every communicator of the group so that nothing hangs, and report the first error
+        if (rc == RTPBR_OK) rc = rt_fail(RTPBR_EHIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
+        for (int i = 0; i < n; i++) abort_comm(ctxs[i]);
+        return rc;
+    }
     for (int i = 0; i < n; i++)
         if (int r = enqueue_unpack(ctxs[i])) return r;
+    for (int i = 0; i < n; i++)
+        if (int r = rt_rccl_check_async(ctxs[i])) return r;
     return RTPBR_OK;
 }
 

@@ -487,7 +487,7 @@ def test_full_size_cornell_1080p(variant, tmp_path, monkeypatch):
     assert np.all(np.isfinite(g.image_pixels)) and g.image_pixels.min() >= 0 and g.image_pixels.max() <= 1
 
 
-def _run_bench(args, nproc=0, timeout=900):
+def _run_bench(args, nproc=0, timeout=900, env=None):
     import json
     import os
     import socket
@@ -498,7 +498,8 @@ def _run_bench(args, nproc=0, timeout=900):
     if nproc:
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    out = subprocess.run(cmd + [os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root)
+    out = subprocess.run(cmd + [os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=root,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads([l for l in out.stdout.split("\n") if l.startswith("{")][-1])
 
@@ -531,6 +532,35 @@ def test_bench_every_workload_single_gpu_contract(workload):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches_timed"] >= 2
     assert abs(j["value"] - 320 * 180 * 8 * 2 / (j["ms_per_step"] * 2 / 1e3) / 1e6) < 0.02 * j["value"]
     assert j["config"]["kernels"].startswith("run-time compiled") and j["jit"]["first_use_s"] > 0
+
+
+def _rccl_stub():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "stubs", "libfake_rccl.so")
+    src = os.path.join(root, "tests", "stubs", "fake_rccl.cpp")
+    if not os.path.exists(stub) or os.path.getmtime(stub) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-L/opt/rocm/lib", "-lamdhip64", "-lrt",
+                        "-o", stub], check=True)
+    return stub
+
+
+@pytest.mark.parametrize("workload,nproc", [("c2", 2), ("src", 3)])
+def test_bench_scale_command_with_one_process_per_rank(workload, nproc):
+    """The command a SCALE run issues — torch.distributed.run, N processes, bench.py --gpus N with its DEFAULT transport:
+    rtpbr_rccl_unique_id on rank 0, the id over the gloo control plane, ncclCommInitRank with N > 1 in every process,
+    rtpbr_gather_tiles per step — on this box's one GPU.  RCCL refuses several ranks on one device, so RTPBR_RCCL_LIB points
+    the library at tests/stubs/libfake_rccl.so, which moves the packed tiles ACROSS the processes (hipIpcMemHandle) and
+    nothing else.  The communicator must report N ranks, every rank must have rendered and gathered, and the frame rank 0
+    holds after the gather must equal the untiled frame bit for bit."""
+    j = _run_bench(["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--workload", workload, "--width", "480", "--height", "270", "--spp", "16",
+                    "--transport", "rccl", "--same-device", "--check-gather", "--no-cpu-baseline"], nproc=nproc,
+                   env={"RTPBR_RCCL_LIB": _rccl_stub(), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    mg = j["multi_gpu"]
+    assert j["n_gpus"] == nproc and mg["rccl_nranks"] == nproc and mg["rccl_rank"] == 0 and mg["rccl_version"] == 99999
+    assert "ncclGather" in mg["transport"] and mg["gathered_equals_untiled"] is True
+    assert [p["rank"] for p in mg["per_rank"]] == list(range(nproc))
+    assert all(p["kernel_ms_per_step"] > 0 and p["gather_ms_per_step"] > 0 for p in mg["per_rank"])
 
 
 def test_bench_default_transport_is_the_c_abi_rccl_gather():
@@ -716,9 +746,7 @@ def test_multi_rank_gather_path_on_one_gpu_with_an_in_process_rccl_stand_in():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     stub = os.path.join(root, "tests", "stubs", "libfake_rccl.so")
-    if not os.path.exists(stub):
-        subprocess.run(["g++", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tests", "stubs", "fake_rccl.cpp"),
-                        "-L/opt/rocm/lib", "-lamdhip64", "-o", stub], check=True)
+    stub = _rccl_stub()
     env = dict(os.environ, RTPBR_RCCL_LIB=stub)
     out = subprocess.run([sys.executable, "-c", _FAKE_RCCL_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))], env=env,
                          capture_output=True, text=True, timeout=600)

@@ -9,7 +9,7 @@ stream, and writes NUMBERS ONLY — inputs and the reference functions' outputs 
 tests/golden/ref_*.npz.  tests/test_oracle_refpin.py then checks oracle/rt_oracle.c against those
 fixtures on any machine (the GPU box has neither /root/reference nor this stand-in's inputs).
 
-    python tools/ref_crosscheck.py v3      # examples/cornell_box/cornell_box_v3/*.py
+    python tools/ref_crosscheck.py v3      # examples/cornell_box/cornell_box_v3/*.py   (v3b8, v3b8_wide: MAX_RAYTRACE 8; 1920x1080)
     python tools/ref_crosscheck.py src     # src/*.py (persistent-ray form)
     python tools/ref_crosscheck.py bunny   # examples/bunny/bunny_sdf_glass.py (sd_bunny, raycast)
     python tools/ref_crosscheck.py v2 | v1 | shortest | scene_demo | tokyo | bunny_glass | bunny_sdf | bunny_sdf_v2
@@ -120,11 +120,25 @@ def grid_pixels(W, H, nx, ny):
 
 
 # =================================================================== Cornell Box v3
-def run_v3(max_raytrace=None, out="ref_v3.npz", grid=(32, 32), SPP=4):
+def run_v3(max_raytrace=None, out="ref_v3.npz", grid=(32, 32), SPP=4, resolution=None):
     """max_raytrace: override of the config constant MAX_RAYTRACE (the BASELINE configs use 4 / 8 bounces with the
-    same functions; cornell_box_v3/config.py:15 ships 3)."""
+    same functions; cornell_box_v3/config.py:15 ships 3).  resolution: override of config.py:3 image_resolution — the
+    reference's OWN config module is executed with that one line replaced (its text is read here at run time, never
+    stored), so SCREEN_PIXEL_SIZE, PIXEL_RADIUS and aspect_ratio are derived by its own expressions (BASELINE configs[1]
+    is this scene at 1920x1080: 16:9 side margins, primary misses, outer wall faces)."""
     ti, _rt = install_standin()
-    sys.path.insert(0, os.path.join(REF, "examples", "cornell_box", "cornell_box_v3"))
+    vdir = os.path.join(REF, "examples", "cornell_box", "cornell_box_v3")
+    sys.path.insert(0, vdir)
+    if resolution is not None:
+        import re
+        import types
+        text = open(os.path.join(vdir, "config.py")).read()
+        text, n = re.subn(r"(?m)^image_resolution\s*=.*$", "image_resolution = (%d, %d)" % tuple(resolution), text)
+        assert n == 1, "cornell_box_v3/config.py: image_resolution line not found"
+        mod = types.ModuleType("config")
+        mod.__file__ = os.path.join(vdir, "config.py")
+        sys.modules["config"] = mod
+        exec(compile(text, mod.__file__, "exec"), mod.__dict__)
     import config, scene, sdf, util, pbr, pathtracer, postprocessor, renderer   # noqa: E401  (the reference's modules)
     from taichi.math import vec2, vec3, vec4
 
@@ -615,6 +629,8 @@ LEGS = dict(
     src_adaptive=lambda: run_src(True, "ref_src_adaptive.npz", 40, (12, 8), 0.05),
     src_spp4_black=lambda: run_src(False, "ref_src_spp4_black.npz", 12, (16, 10), spp=4, black=True),
     v3b8=lambda: run_v3(8, "ref_v3b8.npz", (20, 20), 3),
+    # the headline's geometry through the reference's own functions: 1920x1080 aspect, MAX_RAYTRACE 8, 64 x 36 pixels x 5 spp
+    v3b8_wide=lambda: run_v3(8, "ref_v3b8_wide.npz", (64, 36), 5, resolution=(1920, 1080)),
     v2=lambda: run_script("v2", "cornell_box", "cornell_box_v2", (0, 0, 35.0), _fused, (24, 24), 4),
     v1=lambda: run_script("v1", "cornell_box", "cornell_box", (0, 0, 3.0), _fused, (16, 16), 2),
     shortest=lambda: run_script("shortest", "cornell_box", "cornell_box_shortest", (0, 0, 3.5), _shortest, (24, 24), 4),
