@@ -136,7 +136,7 @@ def make_renderer(wl, device, a, jit=True, bake=True):
         # configuration (rt_jit.hip: ~1-2 s once, then a disk cache), as Taichi JIT-compiles the reference's kernels; falls
         # back to the ahead-of-time instance if hipcc is not available on the box
         r.set_option("jit", 1)
-        r.set_option("jit_bake", 1 if bake else 0)
+        r.set_option("jit_bake", 2 if bake else 0)       # scene, configuration AND the camera frame baked: a fixed-camera offline render
     else:
         r.set_option("jit", 0)
     for kv in a.opt:
@@ -420,7 +420,7 @@ def main():
                                    + ("" if wl.family == "src" else " + ordered accumulation")
                                    + (f" + 1 RCCL gather of {world} tile sets" if world > 1 else ""),
                        "parallelism": f"tiles{world}" if world > 1 else "single",
-                       "kernels": "run-time compiled for this scene (object table and render configuration baked)" if jit_on
+                       "kernels": "run-time compiled for this scene (object table, render configuration and camera frame baked)" if jit_on
                                   else "ahead-of-time instances",
                        "raycasts_per_unit": round(c.raycasts / max(c.samples, 1), 3),
                        "march_steps_per_raycast": round(c.march_steps / max(c.raycasts, 1), 3)},

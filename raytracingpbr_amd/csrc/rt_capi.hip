@@ -373,6 +373,7 @@ static RtJitKey make_jit_key(int kind, int n_obj, const ObjM* objm, const rtpbr_
         memcpy(&key.extra[3], &P.box_4rho2m, 4);
         const int ints[7] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes};
         memcpy(key.ints, ints, sizeof ints);
+        if (key.baked == 2) memcpy(key.cam_words, &P.cam, sizeof key.cam_words);
     }
     return key;
 }
@@ -662,7 +663,6 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
-    c->deposits_host = 0;
     c->ev_used = 0;
     c->evp_used = 0;
     c->timed = true;
@@ -820,18 +820,6 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             c->sample_base += (uint32_t)K;
             left -= K;
         }
-        // deposits = valid owned pixels * n
-        unsigned long long valid = 0;
-        for (int tl = 0; tl < P.n_local_tiles; tl++) {
-            int tid = P.rank + tl * P.world;
-            if (tid >= P.ntx * P.nty) continue;
-            int ty = tid / P.ntx, tx = tid % P.ntx;
-            int w = c->cfg.width - tx * P.tile_w, h = c->cfg.height - ty * P.tile_h;
-            if (w > P.tile_w) w = P.tile_w;
-            if (h > P.tile_h) h = P.tile_h;
-            valid += (unsigned long long)w * h;
-        }
-        c->deposits_host = valid * (unsigned long long)n;
     }
     HIP_TRY(hipEventRecord(c->ev_total1, c->stream));
     HIP_TRY(hipGetLastError());
@@ -934,7 +922,7 @@ extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
     out->march_steps = h.march_steps;
     out->hits = h.hits;
     out->sky_lookups = h.sky_lookups;
-    out->deposits = h.deposits + c->deposits_host;
+    out->deposits = h.deposits;
     return RTPBR_OK;
 }
 
@@ -951,7 +939,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     else if (!strcmp(name, "march_steps")) *out = h.march_steps;
     else if (!strcmp(name, "hits")) *out = h.hits;
     else if (!strcmp(name, "sky_lookups")) *out = h.sky_lookups;
-    else if (!strcmp(name, "deposits")) *out = h.deposits + c->deposits_host;
+    else if (!strcmp(name, "deposits")) *out = h.deposits;
     else if (!strcmp(name, "mlp_wave_evals")) *out = h.mlp_wave_evals;
     else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
     else if (!strncmp(name, "dbg", 3) && name[3] >= '0' && name[3] <= '9' && !name[4]) *out = h.dbg[name[3] - '0'];
@@ -1108,7 +1096,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "precision must be 0 (exactly rounded, the default) or 1 (tolerance flavour: hardware sqrt / rcp / sin / exp, contraction)");
         c->precision = (int)value;
     } else if (!strcmp(key, "jit_bake")) {
-        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "jit_bake must be 0 or 1");
+        if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "jit_bake must be 0, 1 (scene + configuration) or 2 (+ the camera frame: fixed-camera offline renders)");
         c->jit_bake = (int)value;
     } else if (!strcmp(key, "specialize")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "specialize must be 0 or 1");

@@ -41,6 +41,7 @@ struct RtJitKey {
     unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed
     unsigned extra[4];          // box_lazy, box_four_rho, box_rho2m, box_4rho2m (bit patterns)
     int ints[7];                // tile_w, tile_h, ntx, nty, world, shade_lanes, swap_lanes
+    unsigned cam_words[21];     // baked == 2: the camera frame (rt::CamFrame) as well — fixed-camera offline renders
 };
 struct RtJitModule {
     hipModule_t module = nullptr;
@@ -106,7 +107,6 @@ struct rtpbr_ctx {
     int tile_w = 0, tile_h = 0, rank = 0, world = 1;
     // progress
     uint32_t sample_base = 0;
-    unsigned long long deposits_host = 0;
     // options
     long long staging_bytes = 16LL << 30;  // 288 GB of HBM: a whole 1080p x 256 spp step (8.5 GB of samples + 4.2 GB of primary records) is one launch
     int wait_lanes = 24;

@@ -208,6 +208,8 @@ static uint64_t baked_hash(const RtJitKey& key) {
     for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
     for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
     for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
+    if (key.baked == 2)
+        for (int k = 0; k < 21; k++) th = (th ^ key.cam_words[k]) * 1099511628211ull + 2;
     return th;
 }
 
@@ -280,7 +282,14 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         fprintf(f, "static constexpr RtJitCfgWords RT_JIT_CFG_WORDS = {{");
         for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) fprintf(f, "0x%08xu%s", key.cfg_words[k], k + 1 < sizeof(rtpbr_config) / 4 ? ", " : "");
         fprintf(f, "}};\n");
-        fprintf(f, "#define RT_JIT_BAKE_PARAMS(Q) do { rtpbr_config b_ = __builtin_bit_cast(rtpbr_config, RT_JIT_CFG_WORDS); "
+        if (key.baked == 2) {
+            fprintf(f, "struct RtJitCamWords { uint32_t w[21]; };\nstatic constexpr RtJitCamWords RT_JIT_CAM_WORDS = {{");
+            for (int k = 0; k < 21; k++) fprintf(f, "0x%08xu%s", key.cam_words[k], k < 20 ? ", " : "");
+            fprintf(f, "}};\n#define RT_JIT_BAKE_CAM(Q) (Q).cam = __builtin_bit_cast(rt::CamFrame, RT_JIT_CAM_WORDS);\n");
+        } else {
+            fprintf(f, "#define RT_JIT_BAKE_CAM(Q)\n");
+        }
+        fprintf(f, "#define RT_JIT_BAKE_PARAMS(Q) do { RT_JIT_BAKE_CAM(Q) rtpbr_config b_ = __builtin_bit_cast(rtpbr_config, RT_JIT_CFG_WORDS); "
                    "b_.seed = (Q).cfg.seed; b_.frame = (Q).cfg.frame; (Q).cfg = b_; (Q).n_obj = %d; "
                    "(Q).box_lazy = %d; (Q).box_four_rho = __builtin_bit_cast(float, 0x%08xu); (Q).box_rho2m = __builtin_bit_cast(float, 0x%08xu); "
                    "(Q).box_4rho2m = __builtin_bit_cast(float, 0x%08xu); "

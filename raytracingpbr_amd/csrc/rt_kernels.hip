@@ -29,9 +29,14 @@ namespace rt {
 // image_buffer[i,j] += vec4(color, 1) for k = 0..K-1 in order (renderer.py:36)
 __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (uint32_t)P.np) return;
-    int x, y;
-    if (!pixel_of(P, q, x, y)) return;
+    int x = 0, y = 0;
+    const bool valid = q < (uint32_t)P.np && pixel_of(P, q, x, y);
+    // the `deposits` work counter is counted where the deposits happen (one per staged sample added to T7), per wave
+    {
+        const uint32_t n = wave_sum(valid ? (uint32_t)P.K : 0u);
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&P.counters->deposits, (unsigned long long)n);
+    }
+    if (!valid) return;
     float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
     float4 acc = *dst;
     // a pixel's K records (12 bytes each) are contiguous (item-linear staging): fetch them 8 at a time (96 B per lane as
@@ -63,7 +68,6 @@ __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
         acc.w += 1.0f;
     }
     *dst = acc;
-    if (threadIdx.x == 0 && blockIdx.x == 0) { /* deposits are counted on the host: pixels*K */ }
 }
 
 // -------------------------------------------------------------------------------------------

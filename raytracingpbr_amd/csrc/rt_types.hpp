@@ -97,6 +97,7 @@ struct CamFrame {
     float lens_radius;
     float inv_w, inv_h;
 };
+static_assert(sizeof(CamFrame) == 21 * 4, "RtJitKey::cam_words holds a CamFrame");
 
 // one staged sample: its three colour words (the count it adds is 1 by definition)
 struct __attribute__((packed, aligned(4))) StageRec { float r, g, b; };

@@ -34,7 +34,7 @@ def hip(scene, cfg, setup, variant):
     setup(g)
     if variant == "jit_baked":
         g.set_option("jit", 2)            # strict: an error if the run-time instance cannot be used
-        g.set_option("jit_bake", 1)
+        g.set_option("jit_bake", 2)
     else:
         g.set_option("jit", 0)            # the ahead-of-time instances, also where the library would compile one by itself
     return g

@@ -95,6 +95,13 @@ def test_baked_instances_match_oracle_and_golden(name, tmp_path, monkeypatch):
     g = Renderer(case.scene, case.cfg.copy(max_raytrace=case.cfg.max_raytrace + 1))
     g.set_option("jit", 2); g.set_option("jit_bake", 1); case.run(g)
     assert len(glob.glob(str(tmp_path / "*.hsaco"))) == n0 + 1
+    # jit_bake = 2 bakes the camera frame as well (fixed-camera offline renders): same bits, one more code object, and a
+    # moved camera compiles another one
+    n1 = len(glob.glob(str(tmp_path / "*.hsaco")))
+    g = Renderer(case.scene, case.cfg)
+    g.set_option("jit", 2); g.set_option("jit_bake", 2); case.run(g)
+    assert g.counter("jit_active") == 1 and len(glob.glob(str(tmp_path / "*.hsaco"))) == n1 + 1
+    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)) and np.array_equal(bits(g.image_pixels), bits(o.image_pixels))
 
 
 @pytest.mark.parametrize("name", ["src_persistent", "src_persistent_4steps_blackbg", "src_adaptive_sampling"])

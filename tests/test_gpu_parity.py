@@ -460,7 +460,7 @@ def test_full_size_cornell_1080p(variant, tmp_path, monkeypatch):
         r = Renderer(sc, cfg)
         if variant == "jit_baked":
             r.set_option("jit", 2)                       # strict: an error if the run-time instance cannot be used
-            r.set_option("jit_bake", 1)
+            r.set_option("jit_bake", 2)
         else:
             r.set_option("jit", 0)
         return r
