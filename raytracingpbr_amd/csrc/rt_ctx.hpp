@@ -135,7 +135,7 @@ struct rtpbr_ctx {
     bool order_valid = false;
     long long cost_steps = 0;          // bounce-steps recorded in cost_buffer since the last plan
     int grid_blocks = 0;          // src/ form, pool scheduler: workgroups to launch (0 = automatic); tuning / test knob
-    int swap_lanes = 8;
+    int swap_lanes = 0;           // 0 = automatic: 8 in the complete-path pool kernel, 12 in the src/ pool kernel (measured: rt_capi.hip)
     int mlp_lanes = 24;
     int mlp_full = 56;
     int mlp_mfma = 1;

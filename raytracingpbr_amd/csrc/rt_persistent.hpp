@@ -323,6 +323,10 @@ RT_D bool pix_advance(const Params& P, const SrcWave& Wv, PixCtx& X, int steps, 
     int px, py;
     pixel_of(P, X.q, px, py);
     const size_t pi = (size_t)px * g.height + py;
+    // The loop holds only what a roulette kill repeats (stream key, survival probability, one draw): a wave stays in it as
+    // long as ANY of its contexts keeps being killed (about 3.4 rounds for 57 contexts at a kill rate of 0.2), so the
+    // deposit and the camera-ray regeneration — 200 instructions — come after it, once, for the contexts that survived.
+    bool go = false;
     for (;;) {
         if (!fresh && (((uint32_t)X.s & Wv.s_mask) == 0u || X.s >= steps)) break;
         fresh = false;
@@ -338,6 +342,10 @@ RT_D bool pix_advance(const Params& P, const SrcWave& Wv, PixCtx& X, int steps, 
             continue;
         }
         X.col = X.col * (1.0f / p);
+        go = true;
+        break;
+    }
+    if (go) {
         if (X.depth < 1 || X.depth > g.max_raytrace) {
             float4 acc = P.image_buffer[pi];
             acc.x += X.col.x;
@@ -482,7 +490,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     };
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
-    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
+    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
 #endif
 
     for (;;) {
@@ -511,6 +519,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
                 dbg_passes++;
                 dbg_shaded += (unsigned)n_shade;
+#endif
+#if RT_DEBUG_PHASE == 3
+                unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
                 PixCtx X;
                 X.o = X.d = X.col = mk(0, 0, 0);
@@ -552,6 +563,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     have = true;
                     st = SL_EMPTY;
                 }
+#if RT_DEBUG_PHASE == 3
+                { const unsigned long long t = __builtin_readcyclecounter(); dbg_tb_shade += t - tb0; tb0 = t; }
+#endif
                 // free slots take the wave's next items, in order: the j-th free slot gets item next_item + j
                 {
                     const bool want = st == SL_EMPTY && !have;
@@ -586,8 +600,14 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     }
                     next_item += take;
                 }
+#if RT_DEBUG_PHASE == 3
+                { const unsigned long long t = __builtin_readcyclecounter(); dbg_tb_load += t - tb0; tb0 = t; }
+#endif
                 bool ready = false;
                 if (have) ready = pix_advance<KIND>(P, Wv, X, steps, fresh, n_samples, n_dep);
+#if RT_DEBUG_PHASE == 3
+                { const unsigned long long t = __builtin_readcyclecounter(); dbg_tb_adv += t - tb0; tb0 = t; }
+#endif
                 if (ready) {
                     pool[G_OX][lane] = f2u(X.o.x); pool[G_OY][lane] = f2u(X.o.y); pool[G_OZ][lane] = f2u(X.o.z);
                     pool[G_DX][lane] = f2u(X.d.x); pool[G_DY][lane] = f2u(X.d.y); pool[G_DZ][lane] = f2u(X.d.z);
@@ -764,7 +784,12 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         } else {
             atomicMax(&P.counters->dbg[11], life);
         }
-#if RT_DEBUG_PHASE == 2
+#if RT_DEBUG_PHASE == 3
+        atomicAdd(&P.counters->dbg[28], dbg_tb_shade >> 10);
+        atomicAdd(&P.counters->dbg[29], dbg_tb_load >> 10);
+        atomicAdd(&P.counters->dbg[30], dbg_tb_adv >> 10);
+        if (false) {
+#elif RT_DEBUG_PHASE == 2
         {   // histogram of the wave lifetimes (bins of 16 Mcycles): light waves in dbg[16..31]
             const unsigned bin = (unsigned)(life >> 24);
             if (!heavy) atomicAdd(&P.counters->dbg[16 + (bin < 15u ? bin : 15u)], 1ull);

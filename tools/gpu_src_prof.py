@@ -46,7 +46,9 @@ if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
                       "light_wave_life_Mcycles_max": round(d[11] / 1e6, 1),
                       "lanes_per_march_iter": round(d[7] / max(d[6], 1), 2),
                       "cycles_per_pass": round((d[0] << 10) / max(d[4], 1)), "cycles_per_march_iter": round((d[2] << 10) / max(d[6], 1))}), flush=True)
-    if 'RT_DEBUG_PHASE=2' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
+    if 'RT_DEBUG_PHASE=3' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
+        print(json.dumps({'B_pass_Mcycles': {'unpack_and_shade': d[28], 'fresh_item_loads': d[29], 'roulette_deposit_regen_writeback': d[30], 'whole_B_and_dispatch': d[0]}}), flush=True)
+    elif 'RT_DEBUG_PHASE=2' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
         print(json.dumps({'light_wave_life_hist_16Mcycle_bins': d[16:32]}), flush=True)
     elif sched == 1 and d[16]:
         print(json.dumps({"wave0": {"life_Mcycles": round(d[16] / 1e6, 1), "B_Mcycles": round(d[17] / 1e6, 1), "march_Mcycles": round(d[18] / 1e6, 1), "march_iters": d[19],
