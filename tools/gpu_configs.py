@@ -19,7 +19,8 @@ def run(name, sc, cfg, spp, env=None, envexp=1.8, tiles=None, chunk=None, warm=1
     if env is not None: r.set_env(env, envexp, 2.2)
     if any(o.type == SHAPE.BUNNY for o in sc.objects): r.set_shape_data(SHAPE.BUNNY, load_bunny_weights())
     if tiles: r.set_tiles(*tiles)
-    for k, v in json.loads(os.environ.get("OPTS", "{}")).items(): r.set_option(k, v)
+    # what bench.py times unless OPTS says otherwise: the run-time instance of the scene, everything baked
+    for k, v in json.loads(os.environ.get("OPTS", '{"jit": 1, "jit_bake": 2}')).items(): r.set_option(k, v)
     r.sample(warm); r.sync()
     chunk = chunk or spp
     tr_tot, tot_tot, samples, c = 0.0, 0.0, 0, None
@@ -45,9 +46,9 @@ run("C4_tokyo_ibl_4k_512spp_rank0of4", src_scene(aspect=16 / 9, tokyo=True), Con
 tw, th = default_tile(7680, 4320, 8)
 spp5 = int(os.environ.get("C5_SPP", "4096"))
 run(f"C5_cornell_8k_{spp5}spp_rank0of8", cornell_box("v3", aspect=16 / 9), Config.cornell_v3(7680, 4320, 0, 8), spp5, tiles=(tw, th, 0, 8), chunk=256)
-run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4)
-run("src_1080p_persistent_256steps", src_scene(aspect=16 / 9), Config.src(1920, 1080, 0, 1), 256, env=env3k, envexp=1.4)
-run("src_4k_persistent_256steps", src_scene(aspect=16 / 9), Config.src(3840, 2160, 0, 1), 256, env=env3k, envexp=1.4)
+run("src_768x432_persistent_256steps", src_scene(aspect=768 / 432), Config.src(768, 432, 0, 1), 256, env=env3k, envexp=1.4, warm=256)      # (a first launch has no cost plan yet)
+run("src_1080p_persistent_256steps", src_scene(aspect=16 / 9), Config.src(1920, 1080, 0, 1), 256, env=env3k, envexp=1.4, warm=256)
+run("src_4k_persistent_256steps", src_scene(aspect=16 / 9), Config.src(3840, 2160, 0, 1), 256, env=env3k, envexp=1.4, warm=256)
 if not LIST:
     path = os.path.join(ROOT, "gpurun_out", "configs.json")
     if only and os.path.exists(path):            # per-config invocations accumulate into one file
