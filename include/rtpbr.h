@@ -342,7 +342,10 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * and of a wave's share of the frame in march iterations; defaults 48, 8), "heavy_own" (pixels per heavy wave, <= 128,
  * default 80), "tiny_own" / "tiny_waves" (the very heaviest pixels: waves of at most tiny_own pixels, tiny_waves of them —
  * a quarter of the grid when the launch is as long as its longest chain), "heavy_prio" (heavy waves raise their issue
- * priority),
+ * priority), "age_tune" (1, default: the light waves' shares are weighted by the residency slot of their block — the k-th
+ * block of a CU is the k-th oldest wave of its SIMD and the issue arbiter favours the older wave — with weights the library
+ * tunes from the lifetimes it measures, so that the waves of a SIMD end together; 0 = equal shares), "age_weights" (fixed
+ * weights instead, one hex digit per slot, oldest first),
  * "primary_split" (primary raycasts in their own coherent lock-step kernel with wave-level
  * object culling; pool scheduler, analytic shapes: 0 never, 1 for launches of >= 2^23 samples
  * (default), 2 always), "specialize" (1: use the instance compiled

@@ -719,6 +719,10 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 P.src_track = c->src_track;
                 P.leave_x8 = c->leave_x8;
                 P.tiny_own = c->tiny_own;
+                P.n_cu = c->n_cu;
+                P.age_on = c->age_on;
+                P.age_pack = 0;
+                for (int k = 0; k < 8; k++) P.age_pack |= (uint32_t)(c->age_w[k] & 15) << (4 * k);
                 if (c->src_plan) {
                     if (c->plan_np != (size_t)P.np) {
                         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -730,13 +734,16 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                         c->cost_steps = 0;
                         HIP_TRY(hipMalloc(&c->cost_buffer, (size_t)P.np * sizeof(uint32_t)));
                         HIP_TRY(hipMalloc(&c->order, (size_t)P.np * sizeof(uint32_t)));
-                        if (!c->plan) HIP_TRY(hipMalloc(&c->plan, sizeof(PlanBuf)));
+                        if (!c->plan) {
+                            HIP_TRY(hipMalloc(&c->plan, sizeof(PlanBuf)));
+                            HIP_TRY(hipMemsetAsync(c->plan, 0, sizeof(PlanBuf), c->stream));
+                        }
                         HIP_TRY(hipMemsetAsync(c->cost_buffer, 0, (size_t)P.np * sizeof(uint32_t), c->stream));
                         c->plan_np = (size_t)P.np;
                     }
                     if (c->cost_steps >= c->plan_interval) {
                         launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
-                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, c->stream);
+                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), c->stream);
                         c->order_valid = true;
                         c->cost_steps = 0;
                     }
@@ -1053,6 +1060,18 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "src_track")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "src_track must be 0 or 1");
         c->src_track = (int)value;
+    } else if (!strcmp(key, "age_weights")) {
+        // one hex digit per residency slot, oldest first (0x88888 = equal shares); 0 switches the weighting off
+        if (value < 0 || value > 0xffffffffLL) return fail(RTPBR_EINVAL, "age_weights must be 0 (off) or up to 8 hex digits, one per residency slot");
+        c->age_on = value != 0 ? 2 : 0;
+        int nd = 0;
+        for (long long v = value; v; v >>= 4) nd++;
+        for (int k = 0; k < 8; k++) c->age_w[k] = k < nd ? (int)((value >> (4 * (nd - 1 - k))) & 15) : 8;
+        for (int k = 0; k < 8; k++)
+            if (c->age_w[k] == 0) c->age_w[k] = 1;
+    } else if (!strcmp(key, "age_tune")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "age_tune must be 0 (equal shares) or 1 (self-tuned age-weighted shares)");
+        c->age_on = (int)value;
     } else if (!strcmp(key, "tiny_waves")) {
         if (value < 0 || value > 65535) return fail(RTPBR_EINVAL, "tiny_waves must be 0 .. 65535");
         c->tiny_waves = (int)value;

@@ -25,7 +25,7 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, hipStream_t st);
+                 int tiny_waves, int n_cu, int n_cls, hipStream_t st);
 }  // namespace rt
 
 // run-time compiled per-scene instances (rt_jit.hip)
@@ -121,6 +121,8 @@ struct rtpbr_ctx {
     int src_plan = 1;             // 1 = re-plan the ownership from the measured per-pixel cost
     int plan_interval = 64;       // ... once at least this many bounce-steps have been recorded since the last plan
     int heavy_own = 80;           // pixels per heavy wave (<= 128)
+    int age_on = 1;               // age-weighted shares of the light waves (residency slot k of a CU = k-th oldest wave of its SIMD)
+    int age_w[8] = {8, 8, 8, 8, 8, 8, 8, 8};
     int tiny_waves = 64;          // small heavy waves for the very heaviest pixels (a quarter of the grid when the launch is chain-bound)
     int tiny_own = 8;             // pixels per small heavy wave (2 or 4 when the budget allows)
     int leave_x8 = 24;            // a shading pass costs the marching lanes about 3 march iterations

@@ -38,7 +38,11 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_primary(const Params P)
 #endif
 #if RT_JIT_FORM != 0
 // src/ persistent-ray form (pathtrace() of src/pathtracer.py:94-103): `steps` bounce-steps per pixel and launch
-extern "C" __global__ void __launch_bounds__(256, (RT_JIT_WAVES > 5 ? 5 : RT_JIT_WAVES)) rt_jit_persistent_pool(const Params P, int steps) {
+// (RT_JIT_WAVES_SRC: the persistent pool kernel's own occupancy target; the complete-path box instances use 6, this kernel 5)
+#ifndef RT_JIT_WAVES_SRC
+#define RT_JIT_WAVES_SRC (RT_JIT_WAVES > 5 ? 5 : RT_JIT_WAVES)
+#endif
+extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES_SRC) rt_jit_persistent_pool(const Params P, int steps) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);
     persistent_pool_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q, steps);

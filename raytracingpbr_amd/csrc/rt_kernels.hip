@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) plan_hist(const uint32_t* __restrict__ co
 // A pixel is heavy when its own chain of march steps is long against BOTH the frame's mean pixel (mean_x16 / 16 times)
 // and a wave's share of the whole frame in march iterations, total / (64 lanes x waves) (bulk_x16 / 16 times).
 __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uint32_t n_waves, uint32_t heavy_own, uint32_t mean_x16, uint32_t bulk_x16,
-                                                 uint32_t tiny_waves) {
+                                                 uint32_t tiny_waves, uint32_t n_cls) {
     __shared__ uint32_t h[256];
     const uint32_t b = threadIdx.x;
     h[b] = plan->hist[b];
@@ -226,6 +226,51 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         const double chain = top ? (double)bucket_floor(top) : 0.0;
         const double bulk = total / (64.0 * (double)(n_waves ? n_waves : 1u));
         plan->tiny_waves = chain > 3.0 * bulk ? n_waves / 4u : (tiny_waves < n_waves / 8u ? tiny_waves : n_waves / 8u);
+        // ---- age-weighted shares: move every residency slot's weight by (mean lifetime of all light waves / its own)
+        // — with equal shares the five waves of a SIMD end at 75 ... 160 Mcycles because the arbiter favours the older
+        // wave; the weights that make them end together are close to 1 / lifetime after ONE measurement and settle in two or
+        // three.  Weights are 6-bit integers around 16 (entries of `order` per round), at most 4 : 1 apart.
+        if (n_cls >= 2u && n_cls <= 8u) {
+            if (!plan->age_valid || plan->age_cls != n_cls)
+                for (uint32_t c = 0; c < 8u; c++) plan->age_wf[c] = 16.0f;
+            double tot = 0.0, cnt = 0.0;
+            bool have = true;
+            for (uint32_t c = 0; c < n_cls; c++) {
+                if (plan->life_cnt[c] == 0u) have = false;
+                tot += (double)plan->life_sum[c];
+                cnt += (double)plan->life_cnt[c];
+            }
+            if (have && tot > 0.0) {
+                const double mean = tot / cnt;
+                double wsum = 0.0;
+                for (uint32_t c = 0; c < n_cls; c++) {
+                    const double m = (double)plan->life_sum[c] / (double)plan->life_cnt[c];
+                    double f = mean / m;
+                    f = f < 0.6 ? 0.6 : (f > 1.6 ? 1.6 : f);                 // one step moves a weight by at most -40 % / +60 %
+                    plan->age_wf[c] = (float)((double)plan->age_wf[c] * f);
+                    wsum += (double)plan->age_wf[c];
+                }
+                double wmax = 0.0;
+                for (uint32_t c = 0; c < n_cls; c++) {                       // mean weight 16
+                    plan->age_wf[c] = (float)((double)plan->age_wf[c] * 16.0 * (double)n_cls / wsum);
+                    wmax = plan->age_wf[c] > wmax ? plan->age_wf[c] : wmax;
+                }
+                for (uint32_t c = 0; c < n_cls; c++) {
+                    float w = plan->age_wf[c];
+                    w = w < (float)wmax * 0.25f ? (float)wmax * 0.25f : w;
+                    w = w > 60.0f ? 60.0f : w;
+                    plan->age_wf[c] = w;
+                    const uint32_t wi = (uint32_t)(w + 0.5f);
+                    plan->age_w[c] = wi < 1u ? 1u : wi;
+                }
+                plan->age_valid = 1u;
+                plan->age_cls = n_cls;
+            }
+            for (uint32_t c = 0; c < 8u; c++) {
+                plan->life_sum[c] = 0ull;
+                plan->life_cnt[c] = 0u;
+            }
+        }
     }
 }
 // order[cursor[bucket]++] = q, one global atomic per (block, bucket); consumes the costs
@@ -249,14 +294,14 @@ __global__ void __launch_bounds__(256) plan_scatter(uint32_t* __restrict__ cost,
     }
 }
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, hipStream_t st) {
-    (void)hipMemsetAsync(plan, 0, sizeof(PlanBuf), st);
+                 int tiny_waves, int n_cu, int n_cls, hipStream_t st) {
+    (void)hipMemsetAsync(plan, 0, offsetof(PlanBuf, age_valid), st);      // (the self-tuned age weights and the lifetimes survive)
     long long need = ((long long)np + 255) / 256, grid = (long long)n_cu * 8;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(plan_hist, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan);
     hipLaunchKernelGGL(plan_scan, dim3(1), dim3(256), 0, st, plan, np, n_waves, (uint32_t)heavy_own, (uint32_t)mean_x16, (uint32_t)bulk_x16,
-                       (uint32_t)tiny_waves);
+                       (uint32_t)tiny_waves, (uint32_t)n_cls);
     hipLaunchKernelGGL(plan_scatter, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan, order);
 }
 

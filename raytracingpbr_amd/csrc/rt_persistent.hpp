@@ -163,14 +163,18 @@ struct PixCtx {
 // tracked-object march below); the rest is dealt round-robin to the other waves, so every light wave gets the same cost
 // profile and, because the order is kept, starts its own heaviest pixels first in every pass.
 struct SrcWave {
-    uint32_t base, stride; // this wave's pixels in `order`
+    uint32_t base, stride; // this wave's pixels in `order`: base + (k / run) * stride + k % run
+    uint32_t run_inv;      // consecutive entries per round (low 6 bits; 1 = plain strided dealing) | ceil(2^20 / run) << 6
     uint32_t n_own;        // pixels owned
     uint32_t n_items;      // n_own * passes
     uint32_t s_mask;       // residency length - 1 (a power of two), ~0u when the wave keeps its pixels for the whole launch
     int lg_s;              // log2(residency length); 31 when single-pass (s >> 31 == 0)
 };
 RT_D uint32_t own_pixel(const Params& P, const SrcWave& Wv, uint32_t k) {
-    const uint32_t i = Wv.base + k * Wv.stride;
+    // round r = k / run (k < 2^14: (k * ceil(2^20 / run)) >> 20, run <= 63; run = 1: r = k)
+    const uint32_t run = Wv.run_inv & 63u, inv = Wv.run_inv >> 6;
+    const uint32_t r = run > 1u ? (k * inv) >> 20 : k;
+    const uint32_t i = Wv.base + r * Wv.stride + (k - r * run);
     return P.order ? P.order[i] : i;
 }
 
@@ -388,6 +392,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     __shared__ uint32_t tbl_all[4][64];
     stage_objects(P, lds_obj);
 
+    const unsigned long long t_wave0 = __builtin_readcyclecounter();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t (*pool)[64] = pool_all[wave];
@@ -398,6 +403,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     // ---- what this wave owns and how it walks it (all wave-uniform).  Heavy waves first: wave 0 of every block, then
     // wave 1, ... so that they spread over the CUs (a block's four waves sit on the four SIMDs of one CU)
     SrcWave Wv;
+    Wv.run_inv = 1u | (1u << 26);
     const uint32_t nw = gridDim.x * 4u;
     const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * gridDim.x + blockIdx.x));
     const uint32_t np = (uint32_t)P.np;
@@ -446,6 +452,57 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         Wv.base = n_heavy + l;
         Wv.stride = n_lw;
         Wv.n_own = n_light > l ? (n_light - l - 1u) / n_lw + 1u : 0u;
+        // Age-weighted shares.  The k-th resident block of a CU (blockIdx / n_cu: blocks are placed round-robin in launch
+        // order) is the k-th OLDEST wave on its SIMD, and the issue arbiter favours the older wave: with equal shares
+        // the five waves of a SIMD finish one after the other (75 ... 160 Mcycles at 1080p) and the SIMD runs its last
+        // third under-occupied.  Class c takes age_w[c] entries of `order` per round and wave instead of one, so that
+        // all of them can end together; neighbouring entries have similar cost, so every wave still gets a fair sample.
+        const uint32_t n_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
+        const uint32_t n_cls = (gridDim.x + n_cu - 1u) / n_cu;
+        const bool age_plan = P.age_on == 1 && P.order && P.plan->age_valid && P.plan->age_cls == n_cls;
+        if ((P.age_on == 2 || age_plan) && n_cls > 1u && n_cls <= 8u) {
+            const uint32_t G = gridDim.x;
+            const uint32_t c = blockIdx.x / n_cu;
+            // light waves per class and this wave's rank among the light waves of its class (ordered by wave, then block);
+            // heavy waves are h = wave * G + block < n_hw
+            auto heavy_in = [&](uint32_t w, uint32_t cls) {      // heavy waves with wave index w among the blocks of class cls
+                const uint32_t b0 = cls * n_cu, b1 = (cls + 1u) * n_cu < G ? (cls + 1u) * n_cu : G;
+                const uint32_t lim = n_hw > w * G ? n_hw - w * G : 0u;       // blocks b < lim are heavy for this wave index
+                const uint32_t hi = lim < b1 ? lim : b1;
+                return hi > b0 ? hi - b0 : 0u;
+            };
+            uint32_t R = 0, off = 0, n_c = 0, j = 0;
+            for (uint32_t cls = 0; cls < n_cls; cls++) {
+                const uint32_t b0 = cls * n_cu, b1 = (cls + 1u) * n_cu < G ? (cls + 1u) * n_cu : G;
+                uint32_t cnt = 0;
+                for (uint32_t w = 0; w < 4u; w++) cnt += (b1 - b0) - heavy_in(w, cls);
+                const uint32_t wgt = age_plan ? P.plan->age_w[cls] : (P.age_pack >> (4u * cls)) & 15u;
+                if (cls < c) off += cnt * wgt;
+                if (cls == c) n_c = cnt;
+                R += cnt * wgt;
+            }
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: keep all of this in scalar registers)
+            for (uint32_t w = 0; w < wv; w++) j += ((c + 1u) * n_cu < G ? n_cu : G - c * n_cu) - heavy_in(w, c);
+            {
+                const uint32_t b0 = c * n_cu;
+                const uint32_t lim = n_hw > wv * G ? n_hw - wv * G : 0u;
+                const uint32_t hb = lim > b0 ? (lim < blockIdx.x ? lim : blockIdx.x) - b0 : 0u;      // heavy blocks of this class before this one
+                j += (blockIdx.x - b0) - hb;
+            }
+            (void)n_c;
+            const uint32_t wgt = age_plan ? P.plan->age_w[c] : (P.age_pack >> (4u * c)) & 15u;
+            if (R > 0u && wgt > 0u) {
+                const uint32_t full = n_light / R, rem = n_light - full * R;
+                const uint32_t start = off + j * wgt;
+                const uint32_t part = rem > start ? (rem - start < wgt ? rem - start : wgt) : 0u;
+                if (full * wgt + part < 16384u && wgt < 64u) {
+                    Wv.base = n_heavy + start;
+                    Wv.stride = R;
+                    Wv.run_inv = wgt | ((((1u << 20) + wgt - 1u) / wgt) << 6);
+                    Wv.n_own = full * wgt + part;
+                }
+            }
+        }
     }
     const uint32_t S = P.chunk;                                   // residency length when the wave owns more than it can hold
     const bool multi = Wv.n_own > 128u && S < (uint32_t)steps;
@@ -820,6 +877,15 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         atomicAdd(&P.counters->dbg[15], dbg_fast_iters);
     }
 #endif
+    // the light waves' lifetimes, per residency slot: what the next plan tunes the age weights with
+    if (!heavy && P.age_on == 1 && P.order && lane == 0 && Wv.n_own > 0u) {
+        const uint32_t n_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
+        const uint32_t c = blockIdx.x / n_cu;
+        if (c < 8u) {
+            atomicAdd(&P.plan->life_sum[c], (unsigned long long)(__builtin_readcyclecounter() - t_wave0));
+            atomicAdd(&P.plan->life_cnt[c], 1u);
+        }
+    }
     flush_counters(P, L.n_steps, L.n_raycasts, L.n_hits, L.n_sky, n_samples, n_dep);
 }
 

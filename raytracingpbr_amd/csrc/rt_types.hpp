@@ -118,6 +118,16 @@ struct PlanBuf {
     unsigned long long total;     // sum of the costs
     uint32_t n_heavy;             // the first n_heavy entries of `order` are walked by heavy waves
     uint32_t tiny_waves;          // how many waves the small heavy waves may take (the kernel sizes them: 2, 4 or tiny_own pixels each)
+    // ---- everything below survives a re-plan (launch_plan clears the part above only)
+    // Age-weighted shares of the light waves (rt_persistent.hpp): residency slot c of a CU (blockIdx / n_cu) takes
+    // age_w[c] entries of `order` per round.  Self-tuning: every light wave adds its lifetime (cycles) to its slot's sum,
+    // the next plan moves the weights towards equal mean lifetimes.
+    uint32_t age_valid;           // age_w holds tuned weights for age_cls slots
+    uint32_t age_cls;
+    uint32_t age_w[8];
+    float age_wf[8];              // the weights before rounding
+    unsigned long long life_sum[8];
+    uint32_t life_cnt[8];
 };
 
 struct Params {
@@ -142,6 +152,9 @@ struct Params {
     int32_t swap_lanes;     // pool scheduler: swap when this many lanes finished their raycast
     int32_t sparse_lanes;   // src/ pool kernel: tracked-object march steps when at most this many lanes march (0 = only in heavy waves)
     int32_t heavy_own;      // src/ pool kernel: pixels a heavy wave owns (<= 128: they stay resident for the whole launch)
+    int32_t n_cu;           // src/ pool kernel: compute units of the device (blocks are placed round-robin: blockIdx / n_cu = residency slot)
+    int32_t age_on;         // src/ pool kernel: age-weighted shares of the light waves: 0 off, 1 self-tuned (weights in the plan), 2 = age_pack
+    uint32_t age_pack;      // ... entries of `order` per round for the waves of residency slot c: 4 bits each, slot 0 in the lowest
     int32_t tiny_own;       // src/ pool kernel: pixels per small heavy wave (the plan says how many such waves there may be)
     int32_t leave_x8;       // src/ pool kernel: cost of leaving the march loop for a shading pass, in eighths of a march iteration of the wave
     int32_t src_track;      // src/ pool kernel: 1 = tracked-object march steps enabled
@@ -176,7 +189,7 @@ struct Params {
     // write-back), the local pixels ordered by that cost (heaviest first; nullptr = no plan yet: identity), and the plan
     uint32_t* cost_buffer;
     const uint32_t* order;
-    const struct PlanBuf* plan;
+    struct PlanBuf* plan;
     ObjM objm[MAX_OBJ];
 };
 static_assert(sizeof(Params) < 3900, "Params must fit the 4 KB kernarg segment");

@@ -246,6 +246,11 @@ def test_persistent_form_schedulers_agree():
                         ({"scheduler": 1, "plan_interval": 16, "heavy_own": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": 1}, (16, 32)),
                         ({"scheduler": 1, "plan_interval": 4, "heavy_mean_x16": 20, "heavy_bulk_x16": 0, "tiny_own": 2, "tiny_waves": 7, "leave_x8": 1}, (4, 44)),
                         ({"scheduler": 1, "plan_interval": 4, "heavy_mean_x16": 20, "heavy_bulk_x16": 0, "tiny_own": 8, "tiny_waves": 3, "leave_x8": 400, "src_track": 0}, (4, 44)),
+                        # age-weighted shares of the light waves: self-tuned from the lifetimes of the previous launches (a grid of
+                        # several blocks per CU is needed for there to be residency slots: 768 blocks = 3 per CU), fixed weights
+                        ({"scheduler": 1, "plan_interval": 4, "grid_blocks": 768, "residency": 4}, (4, 4, 4, 12, 24)),
+                        ({"scheduler": 1, "plan_interval": 8, "age_weights": 0xf731, "grid_blocks": 1024, "residency": 8}, (8, 40)),
+                        ({"scheduler": 1, "plan_interval": 8, "age_tune": 0}, (8, 40)),
                         ({"scheduler": 1, "src_plan": 0, "sparse_lanes": 64}, (48,))):
         r = Renderer(case.scene, case.cfg)
         case.setup(r)
