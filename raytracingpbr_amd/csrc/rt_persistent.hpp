@@ -878,7 +878,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     }
 #endif
     // the light waves' lifetimes, per residency slot: what the next plan tunes the age weights with
-    if (!heavy && P.age_on == 1 && P.order && lane == 0 && Wv.n_own > 0u) {
+    if (!heavy && P.age_on == 1 && P.plan && lane == 0 && Wv.n_own > 0u) {
         const uint32_t n_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
         const uint32_t c = blockIdx.x / n_cu;
         if (c < 8u) {

@@ -26,7 +26,10 @@ for seed in range(lo, hi):
                      {"plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "tiny_own": 2, "jit": 0},
                      {"plan_interval": 1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "heavy_own": 3, "tiny_waves": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": 1},
                      {"plan_interval": 2, "heavy_mean_x16": 16, "tiny_own": 4, "tiny_waves": 5, "sparse_lanes": 64, "jit": 1, "leave_x8": 4},
-                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1}]
+                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1},
+                     # age-weighted shares: several blocks per CU (residency slots), self-tuned and fixed weights
+                     {"plan_interval": 1, "grid_blocks": 768, "residency": 2, "jit": 1},
+                     {"plan_interval": 2, "grid_blocks": 520, "age_weights": 0x3f1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "tiny_own": 2}]
     for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)
