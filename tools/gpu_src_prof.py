@@ -19,6 +19,9 @@ r.set_option("jit_bake", int(opts.pop("jit_bake", 1)))
 for k, v in opts.items():
     r.set_option(k, int(v))
 r.sample(64)
+for _ in range(int(os.environ.get("WARM", "2")) if steps >= 64 else 0):     # the self-tuned schedule (cost plan, age weights) settles in two launches
+    r.refresh()
+    r.sample(steps)
 r.sync()
 r.sample(steps)
 tr, tot, n = r.last_sample_ms()
