@@ -278,7 +278,10 @@ def test_persistent_form_tile_partition():
     case.setup(full)
     full.sample(20)
     want_ib, want_rb = full.image_buffer, full.ray_buffer
-    for world, tile, opts in ((3, (20, 16), {}), (2, (32, 32), {"grid_blocks": 1, "residency": 4}), (5, (8, 8), {"scheduler": 0})):
+    for world, tile, opts in ((3, (20, 16), {}), (2, (32, 32), {"grid_blocks": 1, "residency": 4}), (5, (8, 8), {"scheduler": 0}),
+                              # the cost plan orders LOCAL pixels (padded edge tiles included): re-planned between the two calls
+                              (3, (20, 16), {"plan_interval": 4, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "tiny_own": 2, "sparse_lanes": 64}),
+                              (2, (16, 8), {"plan_interval": 12, "grid_blocks": 600, "residency": 2})):
         lay = TileLayout(W, H, tile[0], tile[1], world)
         owner = lay.owner_map()
         got_ib, got_rb = np.zeros_like(want_ib), np.zeros_like(want_rb)
