@@ -698,6 +698,65 @@ def test_edge_cases_match_oracle():
         g.set_scene(Scene(objs + objs[:1], False, sc.camera))          # 33 objects > RTPBR_MAX_OBJECTS
 
 
+@pytest.mark.parametrize("scene_kind", ["mirror_ties", "far_camera", "touching", "single_object", "planes_and_none"])
+def test_tracked_march_adversarial_scenes(scene_kind):
+    """The exact tracked-object march of the src/ pool kernel (one object evaluated per step while a Lipschitz bound proves
+    the others farther) on scenes built to break a sloppy bound: EXACT ties (two identical objects mirrored about the
+    camera's plane of symmetry: the bound test is strict, a tie must fall back to the full evaluation and the lower index
+    must win), a camera a thousand units away (the rounding allowance scales with |p|, rays restart from MAX_DIS after an
+    escape), objects that touch (gap 0.001), one object only (nothing to bound: the second distance is 'infinite'), planes
+    and NONE shapes mixed in.  Tracked steps whenever allowed (sparse_lanes 64), every pixel heavy, waves of 2; ahead-of-time
+    and run-time instances; image_buffer, ray_buffer and the counters bit for bit against the oracle."""
+    from raytracingpbr_amd import SHAPE, Camera, Material, SDFObject, Scene, Transform
+    W, H = 48, 27
+    diffuse = Material((0.7, 0.6, 0.5), (1, 1, 1), 1.0, 0.0, 0.0, 1.5)
+    metal = Material((0.9, 0.9, 0.9), (1, 1, 1), 0.1, 1.0, 0.0, 1.2)
+    light = Material((1, 1, 1), (8, 8, 8), 1.0, 0.0, 0.0, 1.0)
+    ground = SDFObject(SHAPE.SPHERE, Transform((0, -100.5, 0), (0, 0, 0), (100, 100, 100)), diffuse)
+    cam = Camera((0, 0.1, 5), (0, 0, 0), (0, 1, 0), 35, W / H, 0.01, 5)
+    if scene_kind == "mirror_ties":
+        objs = [ground] + [SDFObject(t, Transform((sx * 0.8, 0.0, 0.0), (0, 0, 0), (0.4, 0.4, 0.4)), m)
+                           for t, m in ((SHAPE.SPHERE, metal), (SHAPE.BOX, diffuse)) for sx in (-1.0, 1.0)] + \
+               [SDFObject(SHAPE.SPHERE, Transform((0, 2.5, 0), (0, 0, 0), (0.5, 0.5, 0.5)), light)]
+        objs = [objs[0], objs[1], objs[2], objs[5], objs[3], objs[4]]        # spheres first, as the reference's stable sort leaves them
+    elif scene_kind == "far_camera":
+        objs = [ground, SDFObject(SHAPE.SPHERE, Transform((0, 0, 0), (0, 0, 0), (0.5, 0.5, 0.5)), metal),
+                SDFObject(SHAPE.CYLINDER, Transform((1.2, -0.2, 0), (0, 0, 0), (0.3, 0.3, 0.3)), diffuse)]
+        cam = Camera((0, 3, 900), (0, 0, 0), (0, 1, 0), 0.4, W / H, 0.0, 900)
+    elif scene_kind == "touching":
+        objs = [ground, SDFObject(SHAPE.SPHERE, Transform((0, -0.2, 0), (0, 0, 0), (0.299, 0.299, 0.299)), metal),      # 0.001 above the ground
+                SDFObject(SHAPE.SPHERE, Transform((0.599, -0.2, 0), (0, 0, 0), (0.3, 0.3, 0.3)), diffuse),              # 0.0 from its neighbour
+                SDFObject(SHAPE.BOX, Transform((-0.63, -0.2, 0), (0, 0, 0), (0.3, 0.3, 0.3)), light)]
+    elif scene_kind == "single_object":
+        objs = [SDFObject(SHAPE.SPHERE, Transform((0, 0, 0), (0, 0, 0), (1, 1, 1)), metal)]
+    else:
+        objs = [SDFObject(SHAPE.NONE, Transform((0, 0, 0), (0, 0, 0), (1, 1, 1)), diffuse),
+                SDFObject(SHAPE.PLANE, Transform((0, 0, 0), (0, 0, 0), (0, -0.6, 0)), diffuse),
+                SDFObject(SHAPE.SPHERE, Transform((0, 0, 0), (0, 0, 0), (0.6, 0.6, 0.6)), metal),
+                SDFObject(SHAPE.PLANE, Transform((0, 0, 0), (0, 0, 0), (0, -0.6, 0)), light),                              # an exact duplicate: ties on every step
+                SDFObject(SHAPE.BOX, Transform((1.3, 0, 0), (0, 30, 0), (0.3, 0.6, 0.3)), diffuse)]
+    sc = Scene(objs, False, cam, scene_kind)
+    cfg = Config.src(W, H, 11, steps_per_launch=1)
+    cfg.sky_kind = 0
+    o = OracleRenderer(sc, cfg)
+    for n in (6, 10, 24):
+        o.sample(n)
+    co = o.counters()
+    for opts in ({"sparse_lanes": 64, "plan_interval": 4, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "tiny_own": 2, "jit": 0},
+                 {"sparse_lanes": 64, "plan_interval": 8, "heavy_mean_x16": 12, "heavy_bulk_x16": 0, "heavy_own": 5, "tiny_waves": 0, "jit": 2, "jit_bake": 1},
+                 {"sparse_lanes": 64, "src_plan": 0, "grid_blocks": 1, "residency": 4, "jit": 2}):
+        g = Renderer(sc, cfg)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        for n in (6, 10, 24):
+            g.sample(n)
+        cg = g.counters()
+        assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups, cg.deposits) == \
+               (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups, co.deposits), (scene_kind, opts)
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)) and np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), (scene_kind, opts)
+        g.close()
+
+
 _FAKE_RCCL_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
