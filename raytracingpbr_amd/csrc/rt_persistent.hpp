@@ -1,6 +1,6 @@
 // rt_persistent.hpp — the src/ persistent-ray form (src/pathtracer.py:16-103, src/scene.py:59-84): the lock-step kernel
-// (one lane per pixel) and the pool kernel (contexts decoupled from lanes: static strided ownership, pass-major
-// residencies, sparse-wave culling).  Included at the end of rt_trace.hpp, whose LDS ray pool (PoolView, pool_swap),
+// (one lane per pixel) and the pool kernel (contexts decoupled from lanes: cost-ordered ownership with heavy waves and
+// age-weighted shares, pass-major residencies, exact tracked-object march, ski-rental exits).  Included at the end of rt_trace.hpp, whose LDS ray pool (PoolView, pool_swap),
 // counters and object staging it uses; compiled ahead of time (rt_kernels.hip) and per scene at run time (rt_jit_tu.hip).
 #pragma once
 #include "rt_trace.hpp"
@@ -118,9 +118,9 @@ RT_D void persistent_steps_impl(const Params& P, int steps) {
 // wave's LDS slots for shading while the lane takes over a parked context that is ready to
 // march, exactly like trace_paths_pool.
 //
-// Ownership is STATIC and STRIDED (round 3; the round-2 kernel claimed chunks of pixels from a global counter and
-// walked each pixel through all `steps` of the launch): wave g of the NW resident waves owns the pixels q = g + k NW,
-// k < n_own.  A context lives as long as `steps` bounce-steps (~25 ms at 256 steps), so with dynamic claiming the
+// Ownership is STATIC (round 3; the round-2 kernel claimed chunks of pixels from a global counter and walked each pixel
+// through all `steps` of the launch): every resident wave owns a fixed set of pixels, n_own of them — strided over the
+// frame in round 3 (q = g + k NW), over the cost-ordered list since round 4 (struct SrcWave below).  A context lives as long as `steps` bounce-steps (~25 ms at 256 steps), so with dynamic claiming the
 // launch ended with every wave draining 128 contexts of uniformly staggered progress — waves were resident for only
 // 45 % (768x432) / 61 % (1080p) of the kernel (profiles/r03a_src_*).  Now
 //   * strided ownership gives every wave a statistically identical sample of the frame (sky and object pixels alike):
@@ -547,7 +547,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     };
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
-    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
+    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_t_fast = 0, dbg_fast_calls = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
 #endif
 
     for (;;) {
@@ -724,7 +724,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             const int n_ready = __popcll(m_ready);
             int n_done;
             // When to leave the march loop.  Parked READY contexts waiting: as soon as swap_lanes lanes have finished (the
-            // swap is cheap).  None waiting: finished lanes and parked contexts make no progress until the next shading
+            // swap is cheap) — or, the same ski-rental rule with the swap's cost of about half a march iteration, when
+            // the lane-iterations READY contexts have waited for a finished lane reach half the marching lanes: a wave of
+            // 2 ... 8 heavy pixels never has swap_lanes finished lanes and used to march each raycast to its end first.  None waiting: finished lanes and parked contexts make no progress until the next shading
             // pass, which stalls the marching lanes for about leave_x8 / 8 march iterations — leave when the lane-iterations
             // wasted by waiting add up to what leaving costs (ski rental: within 2x of the best fixed batch size for ANY
             // arrival rate — grazing rays finish once per hundreds of iterations, ordinary ones every twenty).
@@ -760,10 +762,15 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                                 max_it = (P.leave_x8 * n_march - waste * 8 + 8 * n_shade0 - 1) / (8 * n_shade0);
                                 max_it = max_it < 1 ? 1 : max_it;
                             }
+#ifdef RT_DEBUG_PHASE
+                            const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
                             const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it);
                             if (n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
 #ifdef RT_DEBUG_PHASE
                             dbg_fast_iters += (unsigned)it;
+                            dbg_t_fast += __builtin_readcyclecounter() - tf0;
+                            dbg_fast_calls++;
 #endif
                         } else if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) {
 #ifdef RT_DEBUG_PHASE
@@ -800,8 +807,8 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #endif
                         n_march = __popcll(__ballot(L.state == ST_MARCH));
                         n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
-                        if (n_ready == 0) waste += n_done + n_shade0;
-                    } while (n_march > 0 && (n_ready > 0 ? n_done < m_swap : waste * 8 < P.leave_x8 * n_march));
+                        waste += n_ready == 0 ? n_done + n_shade0 : (n_done < n_ready ? n_done : n_ready);
+                    } while (n_march > 0 && (n_ready > 0 ? (n_done < m_swap && waste * 2 < n_march + 1) : waste * 8 < P.leave_x8 * n_march));
 #ifdef RT_DEBUG_PHASE
                     tD += __builtin_readcyclecounter() - ts0;      // (cycles of the tracked march loops, reported in place of the dispatch phase)
 #endif
@@ -815,8 +822,8 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
                     n_march = __popcll(__ballot(L.state == ST_MARCH));
                     n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
-                    if (n_ready == 0) waste += n_done + n_shade0;
-                } while (n_march > 0 && (n_ready > 0 ? n_done < m_swap : waste * 8 < P.leave_x8 * n_march));
+                    waste += n_ready == 0 ? n_done + n_shade0 : (n_done < n_ready ? n_done : n_ready);
+                } while (n_march > 0 && (n_ready > 0 ? (n_done < m_swap && waste * 2 < n_march + 1) : waste * 8 < P.leave_x8 * n_march));
                 trk_lb = -1.0f;     // the plain steps did not maintain the bounds
             }
         }
@@ -864,12 +871,12 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             P.counters->dbg[22] = dbg_passes;
             P.counters->dbg[23] = dbg_trk_ok;
             P.counters->dbg[24] = dbg_march_lanes;
-            P.counters->dbg[25] = dbg_trk_rounds;
+            P.counters->dbg[25] = dbg_fast_iters | (dbg_fast_calls << 32);
             P.counters->dbg[26] = dbg_t_trk;
             P.counters->dbg[27] = dbg_t_full2;
             P.counters->dbg[28] = dbg_s_flag;
             P.counters->dbg[29] = dbg_s_done;
-            P.counters->dbg[30] = dbg_s_idle;
+            P.counters->dbg[30] = dbg_t_fast;
             P.counters->dbg[31] = dbg_s_ready | (dbg_s_shade << 32);
         }
         atomicAdd(&P.counters->dbg[12], dbg_full2_iters);

@@ -55,7 +55,7 @@ if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
         print(json.dumps({'light_wave_life_hist_16Mcycle_bins': d[16:32]}), flush=True)
     elif sched == 1 and d[16]:
         print(json.dumps({"wave0": {"life_Mcycles": round(d[16] / 1e6, 1), "B_Mcycles": round(d[17] / 1e6, 1), "march_Mcycles": round(d[18] / 1e6, 1), "march_iters": d[19],
-                                    "tracked_iters": d[20], "full2_iters": d[21], "passes": d[22], "tracked_ok_lanesteps": d[23], "lanesteps": d[24], "tracked_rounds": d[25], "cycles_per_tracked_step": round(d[26] / max(d[20], 1)), "cycles_per_full2_step": round(d[27] / max(d[21], 1)),
+                                    "tracked_iters": d[20], "full2_iters": d[21], "passes": d[22], "tracked_ok_lanesteps": d[23], "lanesteps": d[24], "fast_steps": d[25] & 0xffffffff, "fast_calls": d[25] >> 32, "fast_Mcycles": round(d[30] / 1e6, 1), "cycles_per_tracked_step": round(d[26] / max(d[20], 1)), "cycles_per_full2_step": round(d[27] / max(d[21], 1)),
                                     "per_iter": {"stepping": round(d[24] / max(d[19], 1), 1), "flagged_waiting": round(d[28] / max(d[19], 1), 1), "done_waiting": round(d[29] / max(d[19], 1), 1),
-                                                 "idle_lanes": round(d[30] / max(d[19], 1), 1), "parked_ready": round((d[31] & 0xffffffff) / max(d[19], 1), 1), "parked_to_shade": round((d[31] >> 32) / max(d[19], 1), 1)}}}), flush=True)
+                                                 "parked_ready": round((d[31] & 0xffffffff) / max(d[19], 1), 1), "parked_to_shade": round((d[31] >> 32) / max(d[19], 1), 1)}}}), flush=True)
 r.close()
