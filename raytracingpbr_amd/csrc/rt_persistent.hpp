@@ -547,7 +547,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     };
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
-    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_t_fast = 0, dbg_fast_calls = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
+    unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_disp = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_t_fast = 0, dbg_fast_calls = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
 #endif
 
     for (;;) {
@@ -712,7 +712,11 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             }
         }
 
+#if RT_DEBUG_PHASE == 3
+        RT_PHASE(dbg_t_disp)
+#else
         RT_PHASE(tB)
+#endif
         // ================================================================ march
         {
             int n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -852,6 +856,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         atomicAdd(&P.counters->dbg[28], dbg_tb_shade >> 10);
         atomicAdd(&P.counters->dbg[29], dbg_tb_load >> 10);
         atomicAdd(&P.counters->dbg[30], dbg_tb_adv >> 10);
+        atomicAdd(&P.counters->dbg[31], dbg_t_disp >> 10);
         if (false) {
 #elif RT_DEBUG_PHASE == 2
         {   // histogram of the wave lifetimes (bins of 16 Mcycles): light waves in dbg[16..31]

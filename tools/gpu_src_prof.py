@@ -50,7 +50,7 @@ if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
                       "lanes_per_march_iter": round(d[7] / max(d[6], 1), 2),
                       "cycles_per_pass": round((d[0] << 10) / max(d[4], 1)), "cycles_per_march_iter": round((d[2] << 10) / max(d[6], 1))}), flush=True)
     if 'RT_DEBUG_PHASE=3' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
-        print(json.dumps({'B_pass_Mcycles': {'unpack_and_shade': d[28], 'fresh_item_loads': d[29], 'roulette_deposit_regen_writeback': d[30], 'whole_B_and_dispatch': d[0]}}), flush=True)
+        print(json.dumps({'B_pass_Mcycles': {'unpack_and_shade': d[28], 'fresh_item_loads': d[29], 'roulette_deposit_regen_writeback': d[30], 'B_pass_whole (without dispatch)': d[0], 'dispatch_swap': d[31], 'march': d[2]}}), flush=True)
     elif 'RT_DEBUG_PHASE=2' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
         print(json.dumps({'light_wave_life_hist_16Mcycle_bins': d[16:32]}), flush=True)
     elif sched == 1 and d[16]:
