@@ -83,6 +83,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->stage);
     (void)hipFree(c->primary);
     (void)hipFree(c->cost_buffer);
+    (void)hipFree(c->march_out);
     (void)hipFree(c->order);
     (void)hipFree(c->plan);
     rt_rccl_release(c);
@@ -752,7 +753,41 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                     P.plan = c->plan;
                     c->cost_steps += steps;
                 }
-                if (c->jit_mod) {
+                // A launch of one (or a few) bounce-steps — the way the reference calls pathtrace(), src/renderer.py:29-30 — runs
+                // as the wavefront split of rt_split.hpp: per step gen (roulette / deposit / camera ray), march (the raycasts,
+                // heaviest first from the cost-ordered list), shade.  Same results, same counters.
+                if (c->src_split > 0 && steps <= c->src_split) {
+                    if (c->march_np != (size_t)P.np) {
+                        HIP_TRY(hipStreamSynchronize(c->stream));
+                        (void)hipFree(c->march_out);
+                        c->march_out = nullptr;
+                        c->march_np = 0;
+                        HIP_TRY(hipMalloc(&c->march_out, (size_t)P.np * sizeof(uint32_t)));
+                        c->march_np = (size_t)P.np;
+                    }
+                    P.march_out = c->march_out;
+                    P.wait_lanes = c->split_wait;
+                    int mper = c->jit_mod ? c->jit_mod->march_blocks_per_cu : src_march_blocks_per_cu(c->kind);
+                    if (mper <= 0) mper = 2;
+                    if (c->waves_per_cu > 0) mper = (c->waves_per_cu + 3) / 4;
+                    long long mgrid = (long long)mper * c->n_cu;
+                    const long long need = ((long long)P.np + 255) / 256;
+                    if (mgrid > need) mgrid = need;
+                    if (c->grid_blocks > 0) mgrid = c->grid_blocks;
+                    if (mgrid < 1) mgrid = 1;
+                    for (int i = 0; i < steps; i++) {
+                        P.sample_base = c->sample_base + (uint32_t)i;
+                        if (c->jit_mod) {
+                            if (int r = rt_jit_launch(c->jit_mod->src_gen, P, (unsigned)need, c->stream)) return r;
+                            if (int r = rt_jit_launch(c->jit_mod->src_march, P, (unsigned)mgrid, c->stream)) return r;
+                            if (int r = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)need, c->stream)) return r;
+                        } else {
+                            launch_src_gen(P, c->kind, c->stream);
+                            launch_src_march(P, c->kind, (int)mgrid, c->stream);
+                            launch_src_shade(P, c->kind, c->stream);
+                        }
+                    }
+                } else if (c->jit_mod) {
                     if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
                 } else
                     launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
@@ -920,12 +955,20 @@ extern "C" int rtpbr_unpack_tiles(rtpbr_ctx* c, const void* device_src, int src_
     return RTPBR_OK;
 }
 
+// the kernels add the six work counters up in 64 shards (rt_types.hpp Counters::shard): fold them into the fields
+static void fold_shards(Counters& h) {
+    unsigned long long* f[6] = {&h.march_steps, &h.raycasts, &h.hits, &h.sky_lookups, &h.samples, &h.deposits};
+    for (int s = 0; s < 64; s++)
+        for (int k = 0; k < 6; k++) *f[k] += h.shard[s][k];
+}
+
 extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
     if (!c || !out) return fail(RTPBR_EINVAL, "null argument");
     if (int r = set_dev(c)) return r;
     Counters h;
     HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    fold_shards(h);
     out->samples = h.samples;
     out->raycasts = h.raycasts;
     out->march_steps = h.march_steps;
@@ -943,6 +986,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     Counters h;
     HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    fold_shards(h);
     if (!strcmp(name, "samples")) *out = h.samples;
     else if (!strcmp(name, "raycasts")) *out = h.raycasts;
     else if (!strcmp(name, "march_steps")) *out = h.march_steps;
@@ -1057,6 +1101,12 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         c->heavy_own = (int)value;
         c->order_valid = false;       // the plan's share of heavy pixels was sized for the old value
         c->cost_steps = 0;
+    } else if (!strcmp(key, "src_split")) {
+        if (value < 0 || value > 256) return fail(RTPBR_EINVAL, "src_split must be 0 (never) .. 256 (bounce-steps per launch up to which the wavefront split runs)");
+        c->src_split = (int)value;
+    } else if (!strcmp(key, "split_wait")) {
+        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "split_wait must be 1..64");
+        c->split_wait = (int)value;
     } else if (!strcmp(key, "src_track")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "src_track must be 0 or 1");
         c->src_track = (int)value;

@@ -16,6 +16,10 @@ void launch_accumulate(const Params& P, hipStream_t st);
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
 void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
 int persistent_pool_blocks_per_cu(int kind);
+void launch_src_gen(const Params& P, int kind, hipStream_t st);
+void launch_src_march(const Params& P, int kind, int grid, hipStream_t st);
+int src_march_blocks_per_cu(int kind);
+void launch_src_shade(const Params& P, int kind, hipStream_t st);
 void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st);
 void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
@@ -46,7 +50,8 @@ struct RtJitKey {
 struct RtJitModule {
     hipModule_t module = nullptr;
     hipFunction_t trace = nullptr, primary = nullptr, persistent_pool = nullptr, persistent_steps = nullptr;
-    int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0;
+    hipFunction_t src_gen = nullptr, src_march = nullptr, src_shade = nullptr;      // the wavefront split of one src/ bounce-step (rt_split.hpp)
+    int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0, march_blocks_per_cu = 0;
     std::string path;
     int device = 0;
     int pins = 0;                       // contexts whose last rtpbr_sample() used this instance (never unloaded while > 0)
@@ -131,6 +136,10 @@ struct rtpbr_ctx {
     int heavy_mean_x16 = 48;      // a pixel is heavy when its cost exceeds 3 x the mean pixel ...
     int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)
     uint32_t* cost_buffer = nullptr;   // np x u32
+    uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
+    size_t march_np = 0;
+    int src_split = 2;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never
+    int split_wait = 24;          // ... its march kernel refills when this many lanes are free
     uint32_t* order = nullptr;         // np x u32
     rt::PlanBuf* plan = nullptr;
     size_t plan_np = 0;                // pixels the three buffers are sized for

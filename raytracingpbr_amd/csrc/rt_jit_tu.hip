@@ -47,6 +47,22 @@ extern "C" __global__ void __launch_bounds__(256, RT_JIT_WAVES_SRC) rt_jit_persi
     RT_JIT_BAKE_PARAMS(Q);
     persistent_pool_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q, steps);
 }
+// ... and one bounce-step as a wavefront split (rt_split.hpp): what a launch of ONE step runs
+extern "C" __global__ void __launch_bounds__(256) rt_jit_src_gen(const Params P) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    src_gen_impl<RT_JIT_KIND>(Q);
+}
+extern "C" __global__ void __launch_bounds__(256) rt_jit_src_march(const Params P) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    src_march_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q);
+}
+extern "C" __global__ void __launch_bounds__(256) rt_jit_src_shade(const Params P) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    src_shade_impl<RT_JIT_KIND>(Q);
+}
 extern "C" __global__ void __launch_bounds__(256) rt_jit_persistent_steps(const Params P, int steps) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);

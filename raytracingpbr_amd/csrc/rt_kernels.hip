@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
     // the `deposits` work counter is counted where the deposits happen (one per staged sample added to T7), per wave
     {
         const uint32_t n = wave_sum(valid ? (uint32_t)P.K : 0u);
-        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&P.counters->deposits, (unsigned long long)n);
+        if ((threadIdx.x & 63) == 0 && n) atomicAdd(&P.counters->shard[blockIdx.x & 63u][5], (unsigned long long)n);
     }
     if (!valid) return;
     float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
@@ -383,6 +383,36 @@ void launch_persistent(const Params& P, int kind, int steps, hipStream_t st) {
     else if (kind == KIND_BUNNY) hipLaunchKernelGGL((persistent_steps<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P, steps);
     else if (kind == KIND_MIXED) hipLaunchKernelGGL((persistent_steps<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P, steps);
     else hipLaunchKernelGGL((persistent_steps<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
+}
+// the wavefront split of one src/ bounce-step (rt_split.hpp): gen and shade one lane per local pixel, march on persistent waves
+void launch_src_gen(const Params& P, int kind, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((src_gen<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((src_gen<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((src_gen<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((src_gen<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P);
+}
+void launch_src_march(const Params& P, int kind, int grid, hipStream_t st) {
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((src_march<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((src_march<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((src_march<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((src_march<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P);
+}
+int src_march_blocks_per_cu(int kind) {
+    int per_cu = 0;
+    hipError_t e;
+    if (kind == KIND_BOXES) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, src_march<KIND_BOXES>, 256, 0);
+    else if (kind == KIND_BUNNY) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, src_march<KIND_BUNNY>, 256, 0);
+    else if (kind == KIND_MIXED) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, src_march<KIND_MIXED>, 256, 0);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, src_march<KIND_GENERIC>, 256, 0);
+    return e == hipSuccess ? per_cu : 0;
+}
+void launch_src_shade(const Params& P, int kind, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((src_shade<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((src_shade<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((src_shade<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((src_shade<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P);
 }
 void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st) {
     int grid = (int)((n + 255) / 256);

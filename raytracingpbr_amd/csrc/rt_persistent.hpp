@@ -173,7 +173,7 @@ struct SrcWave {
 RT_D uint32_t own_pixel(const Params& P, const SrcWave& Wv, uint32_t k) {
     // round r = k / run (k < 2^14: (k * ceil(2^20 / run)) >> 20, run <= 63; run = 1: r = k)
     const uint32_t run = Wv.run_inv & 63u, inv = Wv.run_inv >> 6;
-    const uint32_t r = run > 1u ? (k * inv) >> 20 : k;
+    const uint32_t r = run > 1u ? (uint32_t)(((unsigned long long)k * inv) >> 20) : k;      // (64-bit: k * inv reaches 2^34)
     const uint32_t i = Wv.base + r * Wv.stride + (k - r * run);
     return P.order ? P.order[i] : i;
 }
@@ -273,7 +273,7 @@ RT_D void march_step_src_tracked(const Params& P, Lane& L, float& lb, bool can, 
 // cycles: this loop is what shortens it.  Runs until a lane fails its bound (it then waits for the wave's next full
 // evaluation, lb <= 0), a lane finishes its raycast, or max_it steps were taken; returns the steps taken.
 template <int KIND, int NOBJ, uint32_t SIG, int I>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
-RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_it) {
+RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_it, int* why = nullptr) {
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
     int it = 0;
@@ -296,6 +296,9 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_
         it++;
         const bool stop = marching & (!ok | (L.state != ST_MARCH));
         if (__any(stop) | (it >= max_it)) {
+#if RT_DEBUG_PHASE == 4
+            if (why) *why = __any(marching & !ok) ? 2 : (__any(stop) ? 1 : 0);      // bound failed / a raycast ended / max_it
+#endif
             if (marching & !ok) lb = -1.0f;
             break;
         }
@@ -303,15 +306,15 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_
     return it;
 }
 template <int KIND, int NOBJ, uint32_t SIG>
-RT_D int march_fast_src(const Params& P, Lane& L, float& lb, int k, int max_it) {
+RT_D int march_fast_src(const Params& P, Lane& L, float& lb, int k, int max_it, int* why = nullptr) {
     int it = 0;
     if constexpr (NOBJ > 0) {
         static_for<NOBJ, 1>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
-            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i>(P, L, lb, i, max_it);
+            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i>(P, L, lb, i, max_it, why);
         });
     } else {
-        it = march_fast_src_obj<KIND, NOBJ, SIG, -1>(P, L, lb, k, max_it);
+        it = march_fast_src_obj<KIND, NOBJ, SIG, -1>(P, L, lb, k, max_it, why);
     }
     return it;
 }
@@ -405,7 +408,16 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     SrcWave Wv;
     Wv.run_inv = 1u | (1u << 26);
     const uint32_t nw = gridDim.x * 4u;
-    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)wave * gridDim.x + blockIdx.x));
+    // Wave index h: heavy waves are h < n_hw.  Blocks are placed round-robin over the CUs in launch order, so block b is the
+    // (b / n_cu)-th oldest resident block of CU b % n_cu and its wave w sits on SIMD w.  h enumerates the OLDEST blocks first
+    // and, inside a residency class, wave 0 of every CU, then wave 1, ...: heavy waves (the launch's critical path) spread
+    // over all SIMDs of the chip one each before any SIMD gets a second one, and are the oldest wave of their SIMD, which the
+    // issue arbiter serves first.  (Round 4 used h = wave * gridDim + block: with three blocks per CU the heavy waves were
+    // the three wave-0s of a CU — all on one SIMD.)
+    const uint32_t hm_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
+    const uint32_t hm_cls = blockIdx.x / hm_cu, hm_b0 = hm_cls * hm_cu;
+    const uint32_t hm_nb = hm_b0 + hm_cu <= gridDim.x ? hm_cu : gridDim.x - hm_b0;      // blocks in this block's residency class
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hm_b0 * 4u + (uint32_t)wave * hm_nb + (blockIdx.x - hm_b0)));
     const uint32_t np = (uint32_t)P.np;
     // Heavy waves come in two sizes: the very heaviest pixels — the launch's critical path IS one of their chains — sit in
     // small waves (2 .. tiny_own pixels), where a context never waits for a lane and the lean tracked loop runs most of
@@ -464,43 +476,45 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             const uint32_t G = gridDim.x;
             const uint32_t c = blockIdx.x / n_cu;
             // light waves per class and this wave's rank among the light waves of its class (ordered by wave, then block);
-            // heavy waves are h = wave * G + block < n_hw
+            // heavy waves are h < n_hw (h enumerates class, then wave, then block: see above)
             auto heavy_in = [&](uint32_t w, uint32_t cls) {      // heavy waves with wave index w among the blocks of class cls
-                const uint32_t b0 = cls * n_cu, b1 = (cls + 1u) * n_cu < G ? (cls + 1u) * n_cu : G;
-                const uint32_t lim = n_hw > w * G ? n_hw - w * G : 0u;       // blocks b < lim are heavy for this wave index
-                const uint32_t hi = lim < b1 ? lim : b1;
-                return hi > b0 ? hi - b0 : 0u;
+                const uint32_t b0 = cls * n_cu, nb = b0 + n_cu <= G ? n_cu : G - b0;
+                const uint32_t h0 = b0 * 4u + w * nb;                        // h of (class cls, wave w, first block)
+                const uint32_t lim = n_hw > h0 ? n_hw - h0 : 0u;
+                return lim < nb ? lim : nb;
             };
-            uint32_t R = 0, off = 0, n_c = 0, j = 0;
+            uint32_t R = 0, off = 0, j = 0, wmax = 0, wmin = 0xffffffffu;
             for (uint32_t cls = 0; cls < n_cls; cls++) {
                 const uint32_t b0 = cls * n_cu, b1 = (cls + 1u) * n_cu < G ? (cls + 1u) * n_cu : G;
                 uint32_t cnt = 0;
                 for (uint32_t w = 0; w < 4u; w++) cnt += (b1 - b0) - heavy_in(w, cls);
                 const uint32_t wgt = age_plan ? P.plan->age_w[cls] : (P.age_pack >> (4u * cls)) & 15u;
                 if (cls < c) off += cnt * wgt;
-                if (cls == c) n_c = cnt;
                 R += cnt * wgt;
+                wmax = wgt > wmax ? wgt : wmax;
+                wmin = wgt < wmin ? wgt : wmin;
             }
             const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(wave);      // (wave-uniform: keep all of this in scalar registers)
             for (uint32_t w = 0; w < wv; w++) j += ((c + 1u) * n_cu < G ? n_cu : G - c * n_cu) - heavy_in(w, c);
             {
                 const uint32_t b0 = c * n_cu;
-                const uint32_t lim = n_hw > wv * G ? n_hw - wv * G : 0u;
-                const uint32_t hb = lim > b0 ? (lim < blockIdx.x ? lim : blockIdx.x) - b0 : 0u;      // heavy blocks of this class before this one
-                j += (blockIdx.x - b0) - hb;
+                const uint32_t hb = heavy_in(wv, c);                         // the heavy blocks of (class, wave) are its first ones
+                j += (blockIdx.x - b0) - (hb < blockIdx.x - b0 ? hb : blockIdx.x - b0);
             }
-            (void)n_c;
             const uint32_t wgt = age_plan ? P.plan->age_w[c] : (P.age_pack >> (4u * c)) & 15u;
-            if (R > 0u && wgt > 0u) {
-                const uint32_t full = n_light / R, rem = n_light - full * R;
+            // Weighted or plain dealing is ONE decision for the whole grid (the two schemes do not tile `order` together: a
+            // wave that fell back on its own while others dealt by weight would own pixels twice / leave others unowned).
+            // Every wave sees the same R, wmin, wmax: the limits (own_pixel: k < 2^14, run < 64) are tested for the heaviest
+            // class, whose waves own at most (full + 1) * wmax pixels.
+            const uint32_t full = R > 0u ? n_light / R : 0u;
+            if (R > 0u && wmin > 0u && wmax < 64u && (unsigned long long)(full + 1u) * wmax < 16384ull) {
+                const uint32_t rem = n_light - full * R;
                 const uint32_t start = off + j * wgt;
                 const uint32_t part = rem > start ? (rem - start < wgt ? rem - start : wgt) : 0u;
-                if (full * wgt + part < 16384u && wgt < 64u) {
-                    Wv.base = n_heavy + start;
-                    Wv.stride = R;
-                    Wv.run_inv = wgt | ((((1u << 20) + wgt - 1u) / wgt) << 6);
-                    Wv.n_own = full * wgt + part;
-                }
+                Wv.base = n_heavy + start;
+                Wv.stride = R;
+                Wv.run_inv = wgt | ((((1u << 20) + wgt - 1u) / wgt) << 6);
+                Wv.n_own = full * wgt + part;
             }
         }
     }
@@ -547,6 +561,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     };
 #ifdef RT_DEBUG_PHASE
     unsigned long long tB = 0, tD = 0, tA = 0, tc = __builtin_readcyclecounter(), t_start = tc;
+    unsigned long long dbg4[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long dbg_passes = 0, dbg_shaded = 0, dbg_march_iters = 0, dbg_march_lanes = 0, dbg_trk_iters = 0, dbg_trk_ok = 0, dbg_full2_iters = 0, dbg_trk_wait = 0, dbg_trk_rounds = 0, dbg_fast_iters = 0, dbg_tb_shade = 0, dbg_tb_load = 0, dbg_tb_adv = 0, dbg_t_disp = 0, dbg_t_trk = 0, dbg_t_full2 = 0, dbg_t_fast = 0, dbg_fast_calls = 0, dbg_s_flag = 0, dbg_s_done = 0, dbg_s_idle = 0, dbg_s_ready = 0, dbg_s_shade = 0;
 #endif
 
@@ -769,7 +784,16 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
                             const unsigned long long tf0 = __builtin_readcyclecounter();
 #endif
+#if RT_DEBUG_PHASE == 4
+                            int why = 0;
+                            const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it, &why);
+                            dbg4[why]++;
+                            dbg4[3] += (unsigned)k0 == 0u ? 0 : 0;
+                            dbg4[8 + (k0 & 7)] += (unsigned)it;
+                            if (max_it < (1 << 20)) dbg4[3]++;
+#else
                             const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it);
+#endif
                             if (n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
 #ifdef RT_DEBUG_PHASE
                             dbg_fast_iters += (unsigned)it;
@@ -792,6 +816,12 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                         } else {
 #ifdef RT_DEBUG_PHASE
                             const unsigned long long tt0 = __builtin_readcyclecounter();
+#endif
+#if RT_DEBUG_PHASE == 4
+                            dbg4[4] += (unsigned)__popcll(__ballot(marching && L.steps_left == P.cfg.max_raymarch));      // lanes that start a raycast
+                            dbg4[5] += (unsigned)__popcll(__ballot(marching && L.steps_left != P.cfg.max_raymarch && trk_lb <= 0.0f));   // lanes whose bound failed
+                            dbg4[6] += (unsigned)__popcll(__ballot(marching && trk_lb > 0.0f));      // lanes dragged along
+                            dbg4[7] += n_can == n_march ? 1u : 0u;       // all could track, but different objects
 #endif
                             if (marching) march_step_src_full2<KIND, NOBJ, SIG>(P, L, trk_lb);
 #ifdef RT_DEBUG_PHASE
@@ -857,6 +887,11 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         atomicAdd(&P.counters->dbg[29], dbg_tb_load >> 10);
         atomicAdd(&P.counters->dbg[30], dbg_tb_adv >> 10);
         atomicAdd(&P.counters->dbg[31], dbg_t_disp >> 10);
+        if (false) {
+#elif RT_DEBUG_PHASE == 4
+        if (heavy && h == 0) {     // the heaviest wave: why its lean loops end, what its full evaluations are for, lean steps per tracked object
+            for (int i = 0; i < 16; i++) P.counters->dbg[16 + i] = dbg4[i];
+        }
         if (false) {
 #elif RT_DEBUG_PHASE == 2
         {   // histogram of the wave lifetimes (bins of 16 Mcycles): light waves in dbg[16..31]

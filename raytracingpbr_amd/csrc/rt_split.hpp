@@ -1,0 +1,353 @@
+// rt_split.hpp — the src/ persistent-ray form as a WAVEFRONT SPLIT, for launches of one (or a few) bounce-steps: the way the
+// reference itself calls pathtrace() — once per displayed frame, one bounce-step per pixel (src/renderer.py:29-30,
+// src/pathtracer.py:80-103).  A fused launch of many steps is the pool kernel's business (rt_persistent.hpp): there a
+// context lives for hundreds of steps and the LDS pool keeps lanes busy.  With ONE step per launch every context needs at most
+// one raycast, the pool can never batch its shading (16 of 64 slots per pass, measured: the shading passes cost more issue
+// slots than the whole march) and the launch is as long as its longest raycast.  So a bounce-step becomes three kernels over
+// the same ray_buffer (T6), each coherent in what it does:
+//   src_gen     one lane per pixel, frame order: russian_roulette + track_once (src/pathtracer.py:53-77) — roulette, deposit
+//               into image_buffer, camera-ray regeneration — and one word per pixel: "needs a raycast" + the RNG position;
+//   src_march   raycast() (src/scene.py:59-84) only.  Persistent waves are dealt groups of 64 pixels from the COST-ORDERED list of
+//               the plan kernels (heaviest first: the launch's longest raycasts start at t = 0, in the oldest waves, which the
+//               issue arbiter serves first, together, on the tracked-object march), refill finished lanes in registers, and
+//               leave the moved origin plus {hit / miss, nearest object} behind;
+//   src_shade   one lane per pixel, frame order: the rest of raytrace() (src/pathtracer.py:16-36) — surface interaction or
+//               environment lookup, stop tests — and the ray state the next launch starts from.
+// Same device functions as the fused kernels, same RNG stream positions: ray_buffer, image_buffer and the counters are bit
+// for bit those of the other two schedulers (tests/test_gpu_parity.py).
+#pragma once
+#include "rt_persistent.hpp"
+
+namespace rt {
+
+enum { MS_NONE = 0, MS_MARCH = 1, MS_HIT = 2, MS_MISS = 3 };
+// march word of a local pixel: state (2 bits) | nearest object (5 bits) << 2 | RNG draws of this bounce-step so far << 8
+RT_D uint32_t mw_pack(uint32_t state, int idx, uint32_t cnt) { return state | ((uint32_t)idx << 2) | (cnt << 8); }
+
+template <int KIND>
+RT_D void src_gen_impl(const Params& P) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    int px = 0, py = 0;
+    bool valid = q < (uint32_t)P.np && pixel_of(P, q, px, py);
+    const rtpbr_config& g = P.cfg;
+    const size_t pi = (size_t)px * g.height + py;
+    // self-adaptive sampling mask (src/pathtracer.py:97-101)
+    if (valid && g.adaptive_sampling && !(P.diff_pixels[pi] > g.noise_threshold)) valid = false;
+    uint32_t word = MS_NONE, n_samples = 0, n_dep = 0;
+    if (valid) {
+        rtpbr_ray rb = P.ray_buffer[pi];
+        const uint32_t key = rng_key(g.seed, (uint32_t)px, (uint32_t)py, P.sample_base);
+        uint32_t cnt = 0;
+        int depth = rb.depth;
+        // russian_roulette :65-77
+        float p = (depth == 0) ? 1.0f : g.quality_per_sample;
+        p -= (float)depth * (1.0f / (float)g.max_raytrace);
+        if (rng_next(key, cnt) > p) {
+            rb.color[0] = rb.color[1] = rb.color[2] = 0.0f;
+            rb.depth = -depth;
+            n_samples = 1;
+        } else {
+            vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]) * (1.0f / p);
+            // track_once :53-62
+            if (depth < 1 || depth > g.max_raytrace) {
+                float4 acc = P.image_buffer[pi];
+                acc.x += col.x;
+                acc.y += col.y;
+                acc.z += col.z;
+                acc.w += 1.0f;
+                P.image_buffer[pi] = acc;
+                n_dep = 1;
+                vec3 o, d;
+                gen_ray(P, px, py, key, cnt, o, d);
+                rb.origin[0] = o.x; rb.origin[1] = o.y; rb.origin[2] = o.z;
+                rb.direction[0] = d.x; rb.direction[1] = d.y; rb.direction[2] = d.z;
+                col = mk(1, 1, 1);
+                rb.depth = 0;
+            }
+            rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
+            word = mw_pack(MS_MARCH, 0, cnt);
+        }
+        P.ray_buffer[pi] = rb;
+    }
+    if (q < (uint32_t)P.np) P.march_out[q] = word;
+    flush_counters(P, 0, 0, 0, 0, n_samples, n_dep);
+}
+
+// One entry of the march list as the march kernel stages it: local pixel, frame index, march word, ray
+enum { E_Q = 0, E_PI, E_WORD, E_OX, E_OY, E_OZ, E_DX, E_DY, E_DZ,
+#ifdef RT_DEBUG_PHASE
+       E_ITEM,      // instrumented build: the entry's position in the list
+#endif
+       E_COUNT };
+
+template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
+RT_D void src_march_impl(const Params& P) {
+    __shared__ uint32_t cur_all[4][E_COUNT][64];
+    const int lane = threadIdx.x & 63;
+    uint32_t (*cur)[64] = cur_all[threadIdx.x >> 6];
+    Lane L;
+    L.state = ST_IDLE;
+    L.n_steps = L.n_raycasts = L.n_hits = L.n_sky = 0;
+    L.o = L.d = mk(0, 0, 0);
+    L.t = L.w = L.s = L.dist = L.t_eval = 0.0f;
+    L.idx = 0;
+    L.steps_left = 0;
+    uint32_t a_q = 0, a_pi = 0, a_word = 0, a_steps0 = 0;
+    float trk_lb = -1.0f;
+    constexpr bool TRK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
+    const bool trk_ok = TRK && P.cull_ok != 0 && P.src_track != 0;
+    // the list's first n_heavy entries are the plan's heavy pixels: the waves that work them off track from the start
+    const uint32_t n_heavy = (P.order && P.plan) ? P.plan->n_heavy : 0u;
+    // Static dealing of the list, no shared counter (a launch holds ~250 pixels per wave: claims of 64 from one global word
+    // saturate it — 32 k atomics at ~90 per microsecond were a third of a millisecond —, larger claims leave waves without
+    // work): wave h takes the groups of 64 consecutive entries h, h + NW, h + 2 NW, ... — every wave the same cost profile,
+    // its heaviest group first.  h enumerates the oldest blocks of every CU first (as in the pool kernel), so the head of
+    // the list — the launch's longest raycasts — starts at once, one group per SIMD, in the wave the arbiter serves first.
+    const uint32_t NW = gridDim.x * 4u;
+    const uint32_t hm_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
+    const uint32_t hm_b0 = blockIdx.x / hm_cu * hm_cu;
+    const uint32_t hm_nb = hm_b0 + hm_cu <= gridDim.x ? hm_cu : gridDim.x - hm_b0;
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hm_b0 * 4u + (uint32_t)(threadIdx.x >> 6) * hm_nb + (blockIdx.x - hm_b0)));
+    const uint32_t n_groups = (P.total_items + 63u) >> 6;
+    const uint32_t n_g = h < n_groups ? (n_groups - h + NW - 1u) / NW : 0u;      // groups of this wave's sequence
+    const int kwait = P.wait_lanes;
+#ifdef RT_DEBUG_PHASE
+    const unsigned long long t_wave0 = __builtin_readcyclecounter();
+    unsigned dbg_iters = 0, dbg_iters_seq = 0;
+    unsigned long long t_seq_done = 0;
+    uint32_t a_item = 0;
+#endif
+
+    // The sequence is static, so it is PREFETCHED two stages ahead (the loads of a refill are a dependent chain — list entry,
+    // then march word and ray — and a wave refills ten times per launch: unhidden, those round trips are as long as the
+    // marching itself).  q_nn = list entries of group k + 2 (in flight), pf_* = words and rays of group k + 1 (in flight),
+    // LDS `cur` = group k, compacted to the entries that need a raycast; refills read LDS only.
+    auto load_q = [&](uint32_t k) -> uint32_t {
+        const uint32_t item = ((k * NW + h) << 6) + (uint32_t)lane;
+        return (k < n_g && item < P.total_items) ? (P.order ? P.order[item] : item) : 0xffffffffu;
+    };
+    uint32_t pf_q = 0xffffffffu, pf_pi = 0, pf_word = MS_NONE;
+    float2 pf_a = make_float2(0, 0), pf_b = make_float2(0, 0), pf_c = make_float2(0, 0);      // origin.xy, (origin.z, direction.x), direction.yz
+    auto load_ray = [&](uint32_t q) {
+        pf_q = q;
+        pf_word = MS_NONE;
+        if (q != 0xffffffffu) {
+            int px, py;
+            pixel_of(P, q, px, py);
+            pf_pi = (uint32_t)px * (uint32_t)P.cfg.height + (uint32_t)py;
+            pf_word = P.march_out[q];
+            const float2* r = reinterpret_cast<const float2*>(P.ray_buffer + pf_pi);      // a ray record is 40 bytes, 8-byte aligned
+            pf_a = r[0];
+            pf_b = r[1];
+            pf_c = r[2];
+        }
+    };
+    uint32_t k_cur = 0, n_cur = 0, c_cur = 0;      // group in `cur`, its entries, entries handed out
+    uint32_t q_nn = load_q(1);
+    load_ray(load_q(0));
+    auto advance_group = [&](bool first) {
+        // pf (group k_cur + 1, or group 0 at the start) -> LDS, compacted; then start the next two loads
+        const bool keep = (pf_word & 3u) == MS_MARCH;
+        const unsigned long long km = __ballot(keep);
+        if (keep) {
+            const int r = wave_rank(km);
+            cur[E_Q][r] = pf_q;
+            cur[E_PI][r] = pf_pi;
+            cur[E_WORD][r] = pf_word;
+            cur[E_OX][r] = __builtin_bit_cast(uint32_t, pf_a.x);
+            cur[E_OY][r] = __builtin_bit_cast(uint32_t, pf_a.y);
+            cur[E_OZ][r] = __builtin_bit_cast(uint32_t, pf_b.x);
+            cur[E_DX][r] = __builtin_bit_cast(uint32_t, pf_b.y);
+            cur[E_DY][r] = __builtin_bit_cast(uint32_t, pf_c.x);
+            cur[E_DZ][r] = __builtin_bit_cast(uint32_t, pf_c.y);
+#ifdef RT_DEBUG_PHASE
+            cur[E_ITEM][r] = (((first ? 0u : k_cur + 1u) * NW + h) << 6) + (uint32_t)lane;
+#endif
+        }
+        lds_wave_fence();
+        n_cur = (uint32_t)__popcll(km);
+        c_cur = 0;
+        if (!first) k_cur++;
+        load_ray(q_nn);
+        q_nn = load_q(k_cur + 2u);
+    };
+    advance_group(true);
+
+    for (;;) {
+        // ================================================================ retire finished raycasts, refill the lanes
+        {
+            const bool done = L.state == ST_HIT || L.state == ST_MISS;
+            if (done) {
+                rtpbr_ray* rb = P.ray_buffer + a_pi;
+                rb->origin[0] = L.o.x; rb->origin[1] = L.o.y; rb->origin[2] = L.o.z;
+                P.march_out[a_q] = mw_pack(L.state == ST_HIT ? MS_HIT : MS_MISS, L.idx, a_word >> 8);
+                // what the raycast cost (fire and forget; the plan kernels consume and clear it)
+                if (P.cost_buffer) atomicAdd(&P.cost_buffer[a_q], L.n_steps - a_steps0);
+#if RT_DEBUG_PHASE == 2
+                {   // histogram of the raycast lengths: dbg[0..7] = <= 16, 32, 64, 128, 256, 511, = 512 (cap), and their step sum per bin in dbg[8..14]
+                    const uint32_t n = L.n_steps - a_steps0;
+                    const int b = n <= 16u ? 0 : n <= 32u ? 1 : n <= 64u ? 2 : n <= 128u ? 3 : n <= 256u ? 4 : n < (uint32_t)P.cfg.max_raymarch ? 5 : 6;
+                    atomicAdd(&P.counters->dbg[b], 1ull);
+                    atomicAdd(&P.counters->dbg[8 + b], (unsigned long long)n);
+                    // where in the cost-ordered list the LONG raycasts (> 128 steps) sit: position bins 0-1k, -2k, -4k, ... (dbg[16..31]);
+                    // raycasts > 256 steps likewise in the high word
+                    if (n > 128u) {
+                        int pb = 0;
+                        for (uint32_t lim = 1024u; pb < 15 && a_item >= lim; lim <<= 1) pb++;
+                        atomicAdd(&P.counters->dbg[16 + pb], 1ull + (n > 256u ? (1ull << 32) : 0ull));
+                    }
+                }
+#endif
+                L.state = ST_IDLE;
+            }
+            for (;;) {
+                const bool want = L.state == ST_IDLE;
+                const unsigned long long wm = __ballot(want);
+                if (wm == 0ull) break;
+                if (c_cur == n_cur) {
+                    if (k_cur + 1u >= n_g) break;          // the sequence is exhausted
+                    advance_group(false);
+                    continue;
+                }
+                const uint32_t r = (uint32_t)wave_rank(wm);
+                const uint32_t avail = n_cur - c_cur;
+                if (want && r < avail) {
+                    const uint32_t e = c_cur + r;
+                    a_q = cur[E_Q][e];
+                    a_pi = cur[E_PI][e];
+                    a_word = cur[E_WORD][e];
+                    L.o = mk(__builtin_bit_cast(float, cur[E_OX][e]), __builtin_bit_cast(float, cur[E_OY][e]), __builtin_bit_cast(float, cur[E_OZ][e]));
+                    L.d = mk(__builtin_bit_cast(float, cur[E_DX][e]), __builtin_bit_cast(float, cur[E_DY][e]), __builtin_bit_cast(float, cur[E_DZ][e]));
+                    a_steps0 = L.n_steps;
+#ifdef RT_DEBUG_PHASE
+                    a_item = cur[E_ITEM][e];
+#endif
+                    // start of raycast() src/scene.py:60-63
+                    L.t = 0.0f;
+                    L.w = P.cfg.omega0;
+                    L.s = 0.0f;
+                    L.dist = P.cfg.max_dis;
+                    L.steps_left = P.cfg.max_raymarch;
+                    L.state = ST_MARCH;
+                    L.n_raycasts++;
+                    trk_lb = -1.0f;
+                }
+                const uint32_t need = (uint32_t)__popcll(wm);
+                c_cur += need < avail ? need : avail;
+                lds_wave_fence();        // (the entries are read before a later advance_group overwrites them)
+            }
+        }
+        const bool seq_done = c_cur == n_cur && k_cur + 1u >= n_g;
+#ifdef RT_DEBUG_PHASE
+        if (seq_done && t_seq_done == 0) { t_seq_done = __builtin_readcyclecounter(); dbg_iters_seq = dbg_iters; }
+#endif
+        if (L.state == ST_IDLE && seq_done) L.state = ST_EXHAUSTED;
+        // ================================================================ march
+        int n_march = __popcll(__ballot(L.state == ST_MARCH));
+        if (n_march == 0) {
+            if (__ballot(L.state != ST_EXHAUSTED) == 0) break;
+            continue;
+        }
+        // leave for a refill when kwait lanes are free — a quarter of the live lanes once the list has run out
+        const int n_active = __popcll(__ballot(L.state != ST_EXHAUSTED));
+        const int cap = n_active >> 2 > 1 ? n_active >> 2 : 1;
+        const int kstar = (seq_done && kwait > cap) ? cap : kwait;
+        bool tracked = false;
+        if constexpr (TRK) tracked = trk_ok && (((k_cur * NW + h) << 6) <= n_heavy + 64u || n_march <= P.sparse_lanes);
+        if (tracked) {
+            if constexpr (TRK) {
+                do {
+                    const bool marching = L.state == ST_MARCH;
+                    const bool can = marching && trk_lb > 0.0f;
+                    const int n_can = __popcll(__ballot(can));
+                    bool fast = false;
+                    int k0 = 0;
+                    if (n_can == n_march) {      // do all of them track the same object?
+                        k0 = __builtin_amdgcn_readlane(L.idx, (int)__builtin_ctzll(__ballot(marching)));
+                        fast = __ballot(marching && L.idx != k0) == 0ull;
+                    }
+                    if (fast) march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, 1 << 20);
+                    else if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can);
+                    else if (marching) march_step_src_full2<KIND, NOBJ, SIG>(P, L, trk_lb);
+#ifdef RT_DEBUG_PHASE
+                    dbg_iters++;
+#endif
+                    n_march = __popcll(__ballot(L.state == ST_MARCH));
+                } while (n_march > 0 && (n_active - n_march) < kstar);
+            }
+        } else {
+            do {
+                if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
+#ifdef RT_DEBUG_PHASE
+                dbg_iters++;
+#endif
+                n_march = __popcll(__ballot(L.state == ST_MARCH));
+            } while (n_march > 0 && (n_active - n_march) < kstar);
+            trk_lb = -1.0f;     // the plain steps did not maintain the bounds
+        }
+    }
+#ifdef RT_DEBUG_PHASE
+    if (lane == 0) {   // per-wave timeline, written over diff_buffer (unused without adaptive sampling; the host reads it back)
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 4u;
+        w[0] = t_wave0;
+        w[1] = t_seq_done;
+        w[2] = __builtin_readcyclecounter();
+        w[3] = (unsigned long long)dbg_iters | ((unsigned long long)dbg_iters_seq << 32);
+    }
+#endif
+    flush_counters(P, L.n_steps, L.n_raycasts, 0, 0, 0, 0);
+}
+
+template <int KIND>
+RT_D void src_shade_impl(const Params& P) {
+    __shared__ ObjFull lds_obj[MAX_OBJ];
+    stage_objects(P, lds_obj);
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_hits = 0, n_sky = 0, n_samples = 0;
+    const uint32_t word = q < (uint32_t)P.np ? P.march_out[q] : 0u;
+    const uint32_t st = word & 3u;
+    if (st == MS_HIT || st == MS_MISS) {
+        int px, py;
+        pixel_of(P, q, px, py);
+        const size_t pi = (size_t)px * P.cfg.height + py;
+        rtpbr_ray rb = P.ray_buffer[pi];
+        vec3 o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
+        vec3 d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
+        vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]);
+        const uint32_t key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, P.sample_base);
+        uint32_t cnt = word >> 8;
+        // raytrace() src/pathtracer.py:16-36 after raycast(); depth += 1 (scene.py:83)
+        int depth = rb.depth + 1;
+        if (st == MS_HIT) {
+            const ObjFull ob = lds_obj[(word >> 2) & 31u];
+            surface_interaction<KIND>(P, ob, o, o, d, col, key, cnt);
+            n_hits = 1;
+            float intensity = brightness(col);
+            col = col * mk(ob.emission[0], ob.emission[1], ob.emission[2]);
+            float visible = brightness(col);
+            bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
+            if (stop) depth = -depth;
+        } else {
+            depth = -depth;
+            col = col * sky_color(P, d);
+            n_sky = 1;
+            if (P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) col = col * (depth < -1 ? 1.0f : 0.0f);
+        }
+        n_samples = 1;
+        rb.origin[0] = o.x; rb.origin[1] = o.y; rb.origin[2] = o.z;
+        rb.direction[0] = d.x; rb.direction[1] = d.y; rb.direction[2] = d.z;
+        rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
+        rb.depth = depth;
+        P.ray_buffer[pi] = rb;
+    }
+    flush_counters(P, 0, 0, n_hits, n_sky, n_samples, 0);
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) src_gen(const Params P) { src_gen_impl<KIND>(P); }
+template <int KIND>
+__global__ void __launch_bounds__(256) src_march(const Params P) { src_march_impl<KIND>(P); }
+template <int KIND>
+__global__ void __launch_bounds__(256) src_shade(const Params P) { src_shade_impl<KIND>(P); }
+
+}  // namespace rt

@@ -38,18 +38,7 @@ RT_D void flush_counters(const Params& P, uint32_t steps, uint32_t raycasts, uin
         if (deposits) atomicAdd(&blk[5], (unsigned long long)deposits);
     }
     __syncthreads();
-    if (threadIdx.x < 6 && blk[threadIdx.x] != 0) {
-        unsigned long long* dst = &P.counters->samples;   // placeholder, set below
-        switch (threadIdx.x) {
-            case 0: dst = &P.counters->march_steps; break;
-            case 1: dst = &P.counters->raycasts; break;
-            case 2: dst = &P.counters->hits; break;
-            case 3: dst = &P.counters->sky_lookups; break;
-            case 4: dst = &P.counters->samples; break;
-            default: dst = &P.counters->deposits; break;
-        }
-        atomicAdd(dst, blk[threadIdx.x]);
-    }
+    if (threadIdx.x < 6 && blk[threadIdx.x] != 0) atomicAdd(&P.counters->shard[blockIdx.x & 63u][threadIdx.x], blk[threadIdx.x]);
 }
 
 // Stage the per-lane-indexed object table (T4: transform + material) in LDS.
@@ -816,3 +805,4 @@ __global__ void __launch_bounds__(256, pool_waves(KIND)) trace_paths_pool(const 
 }  // namespace rt
 
 #include "rt_persistent.hpp"   // the src/ persistent-ray kernels (same namespace; uses the pool above)
+#include "rt_split.hpp"        // ... and their wavefront split for launches of one bounce-step

@@ -109,6 +109,11 @@ struct Counters {
     unsigned long long mlp_wave_evals, mlp_lane_evals;
     // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; "dbg0".."dbgf"
     unsigned long long dbg[32];
+    // The six work counters are ADDED UP here by the kernels: 64 shards of one cache line each, shard = blockIdx % 64, word k =
+    // march_steps, raycasts, hits, sky_lookups, samples, deposits (flush_counters).  One word per counter saturates at ~90
+    // atomics per microsecond: the 8 100 blocks of a one-lane-per-pixel kernel at 1080p took 0.1 ms for that alone.  The host
+    // folds the shards into the fields above when it reads them (rt_capi.hip).
+    unsigned long long shard[64][16];
 };
 
 // The plan of the src/ pool kernel's cost-ordered ownership (device memory; written by the plan kernels, rt_kernels.hip)
@@ -188,6 +193,7 @@ struct Params {
     // src/ pool kernel, cost-ordered ownership (rt_plan.hpp): march steps per local pixel since the last plan (accumulated at
     // write-back), the local pixels ordered by that cost (heaviest first; nullptr = no plan yet: identity), and the plan
     uint32_t* cost_buffer;
+    uint32_t* march_out;    // wavefront split of the src/ form (rt_split.hpp): one word per local pixel between its three kernels
     const uint32_t* order;
     struct PlanBuf* plan;
     ObjM objm[MAX_OBJ];

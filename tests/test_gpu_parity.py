@@ -251,7 +251,17 @@ def test_persistent_form_schedulers_agree():
                         ({"scheduler": 1, "plan_interval": 4, "grid_blocks": 768, "residency": 4}, (4, 4, 4, 12, 24)),
                         ({"scheduler": 1, "plan_interval": 8, "age_weights": 0xf731, "grid_blocks": 1024, "residency": 8}, (8, 40)),
                         ({"scheduler": 1, "plan_interval": 8, "age_tune": 0}, (8, 40)),
-                        ({"scheduler": 1, "src_plan": 0, "sparse_lanes": 64}, (48,))):
+                        ({"scheduler": 1, "src_plan": 0, "sparse_lanes": 64}, (48,)),
+                        # the wavefront split of a bounce-step (round 5: gen / march / shade kernels, rt_split.hpp) — what launches of
+                        # <= src_split steps run: every step split, mixed with fused launches, on the cost-ordered list once a plan
+                        # exists (tracked march for its heavy head), tiny grids, odd claim sizes, ahead-of-time and run-time instances
+                        ({"scheduler": 1, "src_split": 0}, (1, 1, 46)),
+                        ({"scheduler": 1, "src_split": 256}, (48,)),
+                        ({"scheduler": 1, "src_split": 256, "plan_interval": 4, "split_wait": 3, "grid_blocks": 2}, (5, 43)),
+                        ({"scheduler": 1, "src_split": 1, "plan_interval": 2}, (1, 1, 1, 1, 1, 1, 42)),
+                        ({"scheduler": 1, "src_split": 256, "jit": 0, "chunk": 7, "split_wait": 64}, (24, 24)),
+                        ({"scheduler": 1, "src_split": 256, "sparse_lanes": 64, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "plan_interval": 1}, (1, 7, 40)),
+                        ({"scheduler": 1, "src_split": 256, "jit": 1, "jit_bake": 1, "src_track": 0, "waves_per_cu": 4}, (3, 45))):
         r = Renderer(case.scene, case.cfg)
         case.setup(r)
         for k, v in opts.items():
@@ -281,7 +291,8 @@ def test_persistent_form_tile_partition():
     for world, tile, opts in ((3, (20, 16), {}), (2, (32, 32), {"grid_blocks": 1, "residency": 4}), (5, (8, 8), {"scheduler": 0}),
                               # the cost plan orders LOCAL pixels (padded edge tiles included): re-planned between the two calls
                               (3, (20, 16), {"plan_interval": 4, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "tiny_own": 2, "sparse_lanes": 64}),
-                              (2, (16, 8), {"plan_interval": 12, "grid_blocks": 600, "residency": 2})):
+                              (2, (16, 8), {"plan_interval": 12, "grid_blocks": 600, "residency": 2}),
+                              (3, (20, 16), {"src_split": 256, "plan_interval": 4})):
         lay = TileLayout(W, H, tile[0], tile[1], world)
         owner = lay.owner_map()
         got_ib, got_rb = np.zeros_like(want_ib), np.zeros_like(want_rb)

@@ -9,7 +9,10 @@ W, H = int(sys.argv[1]), int(sys.argv[2])
 rest = sys.argv[3:]
 N = int(rest[0]) if rest and "=" not in rest[0] else 256
 opts = dict(kv.split("=") for kv in rest if "=" in kv)
-r = Renderer(src_scene(aspect=W / H), Config.src(W, H, 0, 1))
+cfg = Config.src(W, H, 0, 1)
+if "MAX_RAYMARCH" in os.environ:       # timing experiment only (changes the image): how much of a launch is its longest raycast?
+    cfg.max_raymarch = int(os.environ["MAX_RAYMARCH"])
+r = Renderer(src_scene(aspect=W / H), cfg)
 r.set_env(synthetic_env(3072, 1536, seed=0), 1.4, 2.2)
 r.set_option("jit", 1); r.set_option("jit_bake", 1)
 for k, v in opts.items():
