@@ -257,6 +257,40 @@ def side_config(name, a, device, rank0_of=1):
     return out
 
 
+def frame_latency(a, device, W=768, H=432, frames=200):
+    """One displayed frame the way the reference produces it (/root/reference src/renderer.py:25-32 + src/main.py:62-64):
+    Renderer.render() = SAMPLES_PER_FRAME (1) x pathtrace() of ONE bounce-step + post_process(), then the host reads
+    image_pixels — at the reference's own window size (src/config.py:7).  Wall-clock per frame, every frame synchronised by
+    its read-back; `device_ms_per_frame` is the same loop without the read-back (one sync at the end)."""
+    import numpy as np
+    from raytracingpbr_amd import workloads
+    wl = workloads.get("src", W, H, 1)
+    r = make_renderer(wl, device, a, jit=not a.no_jit)
+    for _ in range(96):                       # the cost plan (64 steps on record) and the run-time instance exist before the timed frames
+        r.render()
+    px = r.image_pixels
+    r.sync()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        r.render()
+        px = r.image_pixels                   # (W, H, 3) float32 to the host, as the GUI / imwrite read the field
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        r.render()
+    r.sync()
+    dt_dev = time.perf_counter() - t0
+    tr, _tot, _n = r.last_sample_ms()
+    split = bool(r.counter("jit_active"))
+    r.close()
+    return {"workload": f"src/ pipeline {W}x{H}: Renderer.render() = sample(1) + post_process(), then image_pixels read to the host — "
+                        f"one displayed frame of the reference (src/renderer.py:25-32, src/main.py:62-64), {frames} frames",
+            "ms_per_frame": round(dt / frames * 1e3, 4), "frames_per_s": round(frames / dt, 1),
+            "device_ms_per_frame": round(dt_dev / frames * 1e3, 4), "sample_kernels_ms": round(tr, 4),
+            "readback_bytes_per_frame": int(np.asarray(px).nbytes), "run_time_kernels": split,
+            "note": "the bounce-step of a one-step launch runs as the wavefront split (gen / march / shade kernels, rt_split.hpp)"}
+
+
 def main():
     a = parse()
     import torch
@@ -479,6 +513,8 @@ def main():
             if a.workload == "c2" and not a.no_configs:
                 out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c3_valu", "c4", "c5", "src", "src_768", "src_4k", "src_1step",
                                                                                  "c2_fast", "c3_fast", "c4_fast", "src_fast")}
+            if a.workload == "c2" and not a.no_configs:
+                out["frame"] = frame_latency(a, local_rank)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(wl, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -334,7 +334,7 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
  * "src_split" (persistent-ray form: a launch of at most this many bounce-steps runs as a wavefront split — per step one
  * coherent kernel for roulette / deposit / camera ray, one for the raycasts on the cost-ordered pixel list, one for shading —
- * instead of the fused pool kernel; 0 = never, default 2), "split_wait" (its march kernel refills lanes when this many are
+ * instead of the fused pool kernel; 0 = never, default 1), "split_wait" (its march kernel refills lanes when this many are
  * free, default 24),
  * "src_track" (same kernel: 1 = tracked-object march steps — a lane that knows a lower bound of every object but the
  * nearest one evaluates only that one, exactly; heavy waves always use them), "sparse_lanes" (... other waves while at

@@ -131,14 +131,15 @@ struct rtpbr_ctx {
     int tiny_waves = 64;          // small heavy waves for the very heaviest pixels (a quarter of the grid when the launch is chain-bound)
     int tiny_own = 8;             // pixels per small heavy wave (2 or 4 when the budget allows)
     int leave_x8 = 24;            // a shading pass costs the marching lanes about 3 march iterations
-    int src_track = 1;            // tracked-object march steps (heavy waves, sparse phases) enabled
+    int src_track = 2;            // tracked-object march steps (heavy waves, sparse phases): 0 off, 1 one-object bounds, 2 also the two-object lean loop
     int heavy_prio = 1;           // heavy waves run at raised issue priority
     int heavy_mean_x16 = 48;      // a pixel is heavy when its cost exceeds 3 x the mean pixel ...
     int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)
     uint32_t* cost_buffer = nullptr;   // np x u32
+    unsigned int* team_counter = nullptr;   // 1024 counters x 64 bytes (split march kernel)
     uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
     size_t march_np = 0;
-    int src_split = 2;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never
+    int src_split = 1;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never (measured at 1080p: one step 0.51 against 0.60 ms fused; two steps 1.3 against 0.65)
     int split_wait = 24;          // ... its march kernel refills when this many lanes are free
     uint32_t* order = nullptr;         // np x u32
     rt::PlanBuf* plan = nullptr;

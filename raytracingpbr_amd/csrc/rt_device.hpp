@@ -583,6 +583,50 @@ RT_D void nearest_exact2(const Params& P, vec3 p, int& idx, float& best, float& 
     // `second` of MAX_DIS in place of a larger distance only makes the tracked steps re-evaluate earlier)
 }
 
+// ... and the THIRD smallest, with the index of the second (rt_persistent.hpp: the two-object lean loop keeps marching on the
+// two nearest objects while a bound proves every other one farther).  best <= second <= third always: inserting d gives
+// min(best, d), med3(best, second, d), med3(second, third, d).  idx2 = an object that attains `second` (any of them when
+// several do: the bound that is derived from `third` then covers the others).
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void nearest_exact3(const Params& P, vec3 p, int& idx, float& best, int& idx2, float& second, float& third) {
+    const int n = NOBJ > 0 ? NOBJ : P.n_obj;
+    ObjTab tab = obj_table();
+    asm volatile("" : "+s"(tab));
+    idx = 0;
+    idx2 = -1;      // no real second object yet (nearest_init: the initial (0, MAX_DIS) is not an object)
+    second = third = 3.0e38f;
+    best = P.cfg.nearest_init ? P.cfg.max_dis : 3.0e38f;
+    bool first = !P.cfg.nearest_init;
+    bool virt = true;       // `best` is not an object's distance yet (the 3e38 / MAX_DIS start value)
+    auto visit = [&](float d, int i) {
+        third = __builtin_amdgcn_fmed3f(second, third, d);
+        const bool lt = first || d < best;
+        const bool mid = !lt && d < second;
+        second = __builtin_amdgcn_fmed3f(best, second, d);
+        idx2 = lt ? (virt ? -1 : idx) : (mid ? i : idx2);
+        best = lt ? d : best;
+        idx = lt ? i : idx;
+        virt = virt && !lt;
+        first = false;
+    };
+    if constexpr (NOBJ > 0) {
+        static_for<NOBJ, 2>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            const ObjM oa = load_obj<SIG, i>(tab);
+            const ObjM ob = load_obj<SIG, (i + 1 < NOBJ ? i + 1 : i)>(tab);
+            if (SIG != 0 || i < P.n_obj) visit(fabs_(signed_distance<KIND>(P, oa, p, RT_SIG_CLS(i), jit_type(i))), i);
+            if constexpr (i + 1 < NOBJ) {
+                if (SIG != 0 || i + 1 < P.n_obj) visit(fabs_(signed_distance<KIND>(P, ob, p, RT_SIG_CLS(i + 1), jit_type(i + 1))), i + 1);
+            }
+        });
+    } else {
+        for (int i = 0; i < n; i++) {
+            const ObjM o = tab[i];
+            visit(fabs_(signed_distance<KIND>(P, o, p)), i);
+        }
+    }
+}
+
 // |sdf| of ONE object chosen by a wave-uniform index (scalar compare-and-branch chain over the unrolled table)
 template <int KIND, int NOBJ, uint32_t SIG>
 RT_D float sdf_object(const Params& P, int kw, vec3 p) {

@@ -228,19 +228,42 @@ RT_D float track_eps(const Params& P, vec3 o) {
 // of the three coordinates (<= ulp(|p|) = eps / 16) and of the two roundings in this update (<= eps / 32 each)
 RT_D float track_decay(float lb, float s_new, float eps) { return fma_(fabs_(s_new), -1.000001f, lb) - 0.25f * eps; }
 
+// What a lane knows from its last full evaluation (round 5: TWO bounds).  lb2 bounds every object but the nearest one
+// (L.idx) from below, lb3 every object but the two nearest (L.idx and k2); <= 0 = not valid.  A ray that grazes ONE surface
+// keeps lb2 valid for hundreds of steps; a ray in the WEDGE between two surfaces (a sphere resting on the ground) has
+// second ~ nearest, so lb2 fails at once — measured on the launch-critical raycasts: every lean attempt failed on its first
+// step and each step cost a full evaluation plus a wasted attempt — while lb3 holds: the two-object loop below.
+struct Trk {
+    float lb2, lb3;
+    int k2;
+};
 template <int KIND, int NOBJ, uint32_t SIG>
-RT_D void march_step_src_full2(const Params& P, Lane& L, float& lb) {
+RT_D void march_step_src_full2(const Params& P, Lane& L, Trk& T) {      // one bound only (src_track = 1)
     const float eps = track_eps(P, L.o);
     int idx;
     float dist, second;
     nearest_exact2<KIND, NOBJ, SIG>(P, L.o, idx, dist, second);
     const float s_new = march_update_src(P, L, idx, dist);
-    lb = track_decay(second - eps, s_new, eps);
+    T.lb2 = track_decay(second - eps, s_new, eps);
+    T.lb3 = -1.0f;
+    T.k2 = idx;
+}
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void march_step_src_full3(const Params& P, Lane& L, Trk& T) {
+    const float eps = track_eps(P, L.o);
+    int idx, idx2;
+    float dist, second, third;
+    nearest_exact3<KIND, NOBJ, SIG>(P, L.o, idx, dist, idx2, second, third);
+    const float s_new = march_update_src(P, L, idx, dist);
+    T.lb2 = track_decay(second - eps, s_new, eps);
+    T.lb3 = idx2 >= 0 ? track_decay(third - eps, s_new, eps) : -1.0f;
+    T.k2 = idx2 >= 0 ? idx2 : idx;
 }
 // `can`: marching lanes whose lb is valid.  Lanes track different objects: one round per distinct object (grazing rays
 // share theirs), each a wave-uniform jump into that object's unrolled code.
-template <int KIND, int NOBJ, uint32_t SIG>
-RT_D void march_step_src_tracked(const Params& P, Lane& L, float& lb, bool can, unsigned long long* dbg_rounds = nullptr) {
+template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
+RT_D void march_step_src_tracked(const Params& P, Lane& L, Trk& T, bool can, unsigned long long* dbg_rounds = nullptr) {
+    float& lb = T.lb2;
     const float eps = track_eps(P, L.o);
     float dk = 0.0f;
     unsigned long long todo = __ballot(can);
@@ -261,6 +284,7 @@ RT_D void march_step_src_tracked(const Params& P, Lane& L, float& lb, bool can, 
     if (ok) {
         const float s_new = march_update_src(P, L, L.idx, dk);
         lb = track_decay(lb, s_new, eps);
+        if constexpr (TWO) T.lb3 = track_decay(T.lb3, s_new, eps);
     } else if (can) {
         lb = -1.0f;
     }
@@ -272,8 +296,9 @@ RT_D void march_step_src_tracked(const Params& P, Lane& L, float& lb, bool can, 
 // whatever it is, so the length of the critical pixel's chain in time is (steps) x (instructions per iteration) x 6
 // cycles: this loop is what shortens it.  Runs until a lane fails its bound (it then waits for the wave's next full
 // evaluation, lb <= 0), a lane finishes its raycast, or max_it steps were taken; returns the steps taken.
-template <int KIND, int NOBJ, uint32_t SIG, int I>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
-RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_it, int* why = nullptr) {
+template <int KIND, int NOBJ, uint32_t SIG, int I, bool TWO = false>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
+RT_D int march_fast_src_obj(const Params& P, Lane& L, Trk& T, int k, int max_it, int* why = nullptr) {
+    float& lb = T.lb2;
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
     int it = 0;
@@ -292,6 +317,7 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_
         if (ok) {
             const float s_new = march_update_src(P, L, k, dk);
             lb = track_decay(lb, s_new, eps);
+            if constexpr (TWO) T.lb3 = track_decay(T.lb3, s_new, eps);
         }
         it++;
         const bool stop = marching & (!ok | (L.state != ST_MARCH));
@@ -305,18 +331,136 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, float& lb, int k, int max_
     }
     return it;
 }
-template <int KIND, int NOBJ, uint32_t SIG>
-RT_D int march_fast_src(const Params& P, Lane& L, float& lb, int k, int max_it, int* why = nullptr) {
+template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
+RT_D int march_fast_src(const Params& P, Lane& L, Trk& lb, int k, int max_it, int* why = nullptr) {
     int it = 0;
     if constexpr (NOBJ > 0) {
         static_for<NOBJ, 1>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
-            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i>(P, L, lb, i, max_it, why);
+            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i, TWO>(P, L, lb, i, max_it, why);
         });
     } else {
-        it = march_fast_src_obj<KIND, NOBJ, SIG, -1>(P, L, lb, k, max_it, why);
+        it = march_fast_src_obj<KIND, NOBJ, SIG, -1, TWO>(P, L, lb, k, max_it, why);
     }
     return it;
+}
+
+// The lean loop on TWO objects: every marching lane tracks the same pair {a, b}, a < b, and holds a valid lb3.  Both objects
+// are evaluated, the nearer one (the lower index on a tie, as nearest() resolves it: objects are visited in index order with a
+// strict `<`) is exactly what nearest() returns while lb3 > min + eps.  lb2 is re-derived on the way (the other object of the
+// pair, or lb3): when the second surface recedes the one-object loop can take over again without a full evaluation.
+template <int KIND, int NOBJ, uint32_t SIG, int A, int B>      // A >= 0: objects A < B of the unrolled table; A < 0: objects a, b of the run-time table
+RT_D int march_fast2_src_pair(const Params& P, Lane& L, Trk& T, int a, int b, int max_it) {
+    ObjTab tab = obj_table();
+    const bool marching = L.state == ST_MARCH;
+    int it = 0;
+    for (;;) {
+        asm volatile("" : "+s"(tab));
+        const float eps = track_eps(P, L.o);
+        float dA, dB;
+        if constexpr (A >= 0) {
+            const ObjM oa = load_obj<SIG, (A >= 0 ? A : 0)>(tab);
+            const ObjM ob = load_obj<SIG, (B >= 0 ? B : 0)>(tab);
+            dA = fabs_(signed_distance<KIND>(P, oa, L.o, RT_SIG_CLS((A >= 0 ? A : 0)), jit_type(A)));
+            dB = fabs_(signed_distance<KIND>(P, ob, L.o, RT_SIG_CLS((B >= 0 ? B : 0)), jit_type(B)));
+        } else {
+            const ObjM oa = tab[a];
+            const ObjM ob = tab[b];
+            dA = fabs_(signed_distance<KIND>(P, oa, L.o));
+            dB = fabs_(signed_distance<KIND>(P, ob, L.o));
+        }
+        const bool lt = dB < dA;
+        const float d = lt ? dB : dA;
+        const float d_other = lt ? dA : dB;
+        const bool ok = marching & (T.lb3 > d + eps) & (!P.cfg.nearest_init | (d < P.cfg.max_dis));
+        if (ok) {
+            const float s_new = march_update_src(P, L, lt ? b : a, d);
+            T.lb2 = track_decay(fmin_(d_other - eps, T.lb3), s_new, eps);
+            T.lb3 = track_decay(T.lb3, s_new, eps);
+            T.k2 = lt ? a : b;
+        }
+        it++;
+        const bool stop = marching & (!ok | (L.state != ST_MARCH));
+        if (__any(stop) | (it >= max_it)) {
+            if (marching & !ok) T.lb3 = T.lb2 = -1.0f;
+            break;
+        }
+    }
+    return it;
+}
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max_it) {      // a < b, wave-uniform
+    int it = 0;
+    if constexpr (NOBJ > 0) {
+        static_for<NOBJ, 1>([&](auto Ia) {
+            constexpr int A = decltype(Ia)::value;
+            if (a == A) {
+                static_for<NOBJ, 1>([&](auto Ib) {
+                    constexpr int B = decltype(Ib)::value;
+                    if constexpr (A < B) {
+                        if (b == B) it = march_fast2_src_pair<KIND, NOBJ, SIG, A, B>(P, L, T, A, B, max_it);
+                    }
+                });
+            }
+        });
+    } else {
+        it = march_fast2_src_pair<KIND, NOBJ, SIG, -1, -1>(P, L, T, a, b, max_it);
+    }
+    return it;
+}
+
+// One iteration of the tracked march for the wave's marching lanes, whichever of its forms applies (all wave-uniform):
+//   1  every lane's lb2 promises to hold and all track the same object: the one-object lean loop (until a lane stops);
+//   2  every lane's lb3 promises to hold and all track the same pair: the two-object lean loop;
+//   3  lanes with a valid lb2 take one tracked step each on their own object — unless too many would have to wait;
+//   4  a full evaluation for everybody (three smallest distances: both bounds fresh).
+// "Promises": lb > the lane's LAST distance — a predictor only (the loops test exactly); it keeps a wedge ray from paying
+// for a one-object attempt that fails on its first step after every full evaluation.  Returns the form taken; `steps` =
+// iterations of a lean loop (1 otherwise).
+// TWO (compile time): the kernel keeps both bounds.  The fused pool kernel does not — its 96 registers have no room for the
+// second bound and the 21 instances of the two-object loop (measured with both compiled in: 13 spills, 1080p 58.7 -> 60.9 ms
+// with the second bound unused, 70.3 ms used: the sparse phases of its light waves are too short to win it back); the march
+// kernel of the wavefront split (rt_split.hpp), whose launch is as long as its slowest raycast, does.
+template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
+RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int max_it, int& steps, unsigned long long* dbg_rounds = nullptr, int* why = nullptr) {
+    const bool marching = L.state == ST_MARCH;
+    const unsigned long long mm = __ballot(marching);
+    const int first = (int)__builtin_ctzll(mm);
+    steps = 1;
+    const bool two = TWO && P.src_track >= 2;
+    // (one bound only: any valid lb2 tries the lean loop, as round 4 did)
+    if (__ballot(marching & (T.lb2 > (two ? L.dist : 0.0f))) == mm) {
+        const int k0 = __builtin_amdgcn_readlane(L.idx, first);
+        if (__ballot(marching && L.idx != k0) == 0ull) {
+            steps = march_fast_src<KIND, NOBJ, SIG, TWO>(P, L, T, k0, max_it, why);
+            return 1;
+        }
+    }
+    if constexpr (TWO) if (two && __ballot(marching & (T.lb3 > L.dist) & (T.k2 != L.idx)) == mm) {
+        const int lo = L.idx < T.k2 ? L.idx : T.k2, hi = L.idx < T.k2 ? T.k2 : L.idx;
+        const int key = lo | (hi << 8);
+        const int key0 = __builtin_amdgcn_readlane(key, first);
+        if (__ballot(marching && key != key0) == 0ull) {
+            if (marching) T.lb2 = -1.0f;      // (re-derived by the loop's first step)
+            steps = march_fast2_src<KIND, NOBJ, SIG>(P, L, T, key0 & 255, key0 >> 8, max_it);
+            return 2;
+        }
+    }
+    const bool can = marching && T.lb2 > 0.0f;
+    const int n_can = __popcll(__ballot(can));
+    if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) {
+        march_step_src_tracked<KIND, NOBJ, SIG, TWO>(P, L, T, can, dbg_rounds);
+        return 3;
+    }
+    if (marching) {
+        if constexpr (TWO) {
+            if (two) march_step_src_full3<KIND, NOBJ, SIG>(P, L, T);
+            else march_step_src_full2<KIND, NOBJ, SIG>(P, L, T);
+        } else {
+            march_step_src_full2<KIND, NOBJ, SIG>(P, L, T);
+        }
+    }
+    return 4;
 }
 
 // Advance a context through the part of its step sequence that needs no marching: roulette,
@@ -544,7 +688,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     const int T = P.shade_lanes;
     const int m_swap = P.swap_lanes;
     // tracked-object march: lower bound of every object but L.idx (<= 0: needs a full evaluation)
-    float trk_lb = -1.0f;
+    Trk Tk = {-1.0f, -1.0f, 0};
     constexpr bool TRK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
     const bool trk_ok = TRK && P.cull_ok != 0 && P.src_track != 0;
 
@@ -723,7 +867,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                 a_q = rec[G_Q];
                 a_key = rec[G_KEY]; a_cnt = rec[G_CNT];
                 src_march_init(L);
-                trk_lb = -1.0f;
+                Tk.lb2 = Tk.lb3 = -1.0f;
             }
         }
 
@@ -759,85 +903,46 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
                     do {
-                        // lanes whose bound is valid try the tracked step; the others wait for the wave's next full
-                        // evaluation, which comes when they are more than a quarter of the tracking ones (or nobody tracks)
-                        const bool marching = L.state == ST_MARCH;
-                        const bool can = marching && trk_lb > 0.0f;
-                        const int n_can = __popcll(__ballot(can));
+                        // one iteration of the tracked march in whichever form applies (tracked_iteration above): a lean loop on one
+                        // or two objects, single tracked steps, or a full evaluation for everybody
 #ifdef RT_DEBUG_PHASE
                         dbg_march_iters++;
                         const uint32_t steps_before = L.n_steps;
+                        const bool marching = L.state == ST_MARCH;
+                        const unsigned long long tt0 = __builtin_readcyclecounter();
 #endif
-                        bool fast = false;
-                        int k0 = 0;
-                        if (n_can == n_march) {      // (n_march > 0 here) do all of them track the same object?
-                            k0 = __builtin_amdgcn_readlane(L.idx, (int)__builtin_ctzll(__ballot(marching)));
-                            fast = __ballot(marching && L.idx != k0) == 0ull;
+                        // the shading pass that waits (if one does) bounds a lean loop's stay: see the ski-rental rule below
+                        int max_it = 1 << 20;
+                        if (n_ready == 0 && n_shade0 > 0) {
+                            max_it = (P.leave_x8 * n_march - waste * 8 + 8 * n_shade0 - 1) / (8 * n_shade0);
+                            max_it = max_it < 1 ? 1 : max_it;
                         }
-                        if (fast) {
-                            // the shading pass that waits (if one does) bounds the stay: see the ski-rental rule below
-                            int max_it = 1 << 20;
-                            if (n_ready == 0 && n_shade0 > 0) {
-                                max_it = (P.leave_x8 * n_march - waste * 8 + 8 * n_shade0 - 1) / (8 * n_shade0);
-                                max_it = max_it < 1 ? 1 : max_it;
-                            }
-#ifdef RT_DEBUG_PHASE
-                            const unsigned long long tf0 = __builtin_readcyclecounter();
-#endif
+                        int it = 1;
 #if RT_DEBUG_PHASE == 4
-                            int why = 0;
-                            const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it, &why);
-                            dbg4[why]++;
-                            dbg4[3] += (unsigned)k0 == 0u ? 0 : 0;
-                            dbg4[8 + (k0 & 7)] += (unsigned)it;
-                            if (max_it < (1 << 20)) dbg4[3]++;
+                        int why = 0;
+                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, &why);
+                        if (form == 1) dbg4[why]++;
+                        dbg4[3 + form]++;                     // [4..7]: iterations by form
+                        dbg4[7 + form] += (unsigned)it;       // [8..11]: steps by form
+#elif defined(RT_DEBUG_PHASE)
+                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds);
 #else
-                            const int it = march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, max_it);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it);
 #endif
-                            if (n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
+                        if (form <= 2 && n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
 #ifdef RT_DEBUG_PHASE
-                            dbg_fast_iters += (unsigned)it;
-                            dbg_t_fast += __builtin_readcyclecounter() - tf0;
-                            dbg_fast_calls++;
-#endif
-                        } else if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) {
-#ifdef RT_DEBUG_PHASE
-                            const unsigned long long tt0 = __builtin_readcyclecounter();
-                            march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can, &dbg_trk_rounds);
-                            dbg_t_trk += __builtin_readcyclecounter() - tt0;
-#else
-                            march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can);
-#endif
-#ifdef RT_DEBUG_PHASE
-                            dbg_trk_iters++;
-                            dbg_trk_ok += (unsigned)__popcll(__ballot(L.n_steps != steps_before));
-                            dbg_trk_wait += (unsigned)(n_march - n_can);
-#endif
-                        } else {
-#ifdef RT_DEBUG_PHASE
-                            const unsigned long long tt0 = __builtin_readcyclecounter();
-#endif
-#if RT_DEBUG_PHASE == 4
-                            dbg4[4] += (unsigned)__popcll(__ballot(marching && L.steps_left == P.cfg.max_raymarch));      // lanes that start a raycast
-                            dbg4[5] += (unsigned)__popcll(__ballot(marching && L.steps_left != P.cfg.max_raymarch && trk_lb <= 0.0f));   // lanes whose bound failed
-                            dbg4[6] += (unsigned)__popcll(__ballot(marching && trk_lb > 0.0f));      // lanes dragged along
-                            dbg4[7] += n_can == n_march ? 1u : 0u;       // all could track, but different objects
-#endif
-                            if (marching) march_step_src_full2<KIND, NOBJ, SIG>(P, L, trk_lb);
-#ifdef RT_DEBUG_PHASE
-                            dbg_t_full2 += __builtin_readcyclecounter() - tt0;
-#endif
+                        {
+                            const unsigned long long dt = __builtin_readcyclecounter() - tt0;
+                            if (form <= 2) { dbg_fast_iters += (unsigned)it; dbg_t_fast += dt; dbg_fast_calls++; }
+                            else if (form == 3) { dbg_trk_iters++; dbg_t_trk += dt; dbg_trk_ok += (unsigned)__popcll(__ballot(L.n_steps != steps_before)); }
+                            else { dbg_full2_iters++; dbg_t_full2 += dt; }
+                            dbg_march_lanes += (unsigned)__popcll(__ballot(L.n_steps != steps_before));
+                            dbg_s_flag += (unsigned)__popcll(__ballot(marching && L.n_steps == steps_before));
+                            dbg_s_done += (unsigned)__popcll(__ballot(!marching && L.state != ST_IDLE));
+                            dbg_s_idle += (unsigned)__popcll(__ballot(L.state == ST_IDLE));
+                            dbg_s_ready += (unsigned)__popcll(m_ready);
+                            dbg_s_shade += (unsigned)__popcll(m_shade);
                         }
-#ifdef RT_DEBUG_PHASE
-                        if (!fast && !(n_can > 0 && n_march - n_can < 1 + (n_can >> 2))) dbg_full2_iters++;
-#endif
-#ifdef RT_DEBUG_PHASE
-                        dbg_march_lanes += (unsigned)__popcll(__ballot(L.n_steps != steps_before));
-                        dbg_s_flag += (unsigned)__popcll(__ballot(marching && L.n_steps == steps_before));
-                        dbg_s_done += (unsigned)__popcll(__ballot(!marching && L.state != ST_IDLE));
-                        dbg_s_idle += (unsigned)__popcll(__ballot(L.state == ST_IDLE));
-                        dbg_s_ready += (unsigned)__popcll(m_ready);
-                        dbg_s_shade += (unsigned)__popcll(m_shade);
 #endif
                         n_march = __popcll(__ballot(L.state == ST_MARCH));
                         n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
@@ -858,7 +963,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                     n_done = __popcll(__ballot(L.state == ST_HIT || L.state == ST_MISS));
                     waste += n_ready == 0 ? n_done + n_shade0 : (n_done < n_ready ? n_done : n_ready);
                 } while (n_march > 0 && (n_ready > 0 ? (n_done < m_swap && waste * 2 < n_march + 1) : waste * 8 < P.leave_x8 * n_march));
-                trk_lb = -1.0f;     // the plain steps did not maintain the bounds
+                Tk.lb2 = Tk.lb3 = -1.0f;     // the plain steps did not maintain the bounds
             }
         }
         RT_PHASE(tA)

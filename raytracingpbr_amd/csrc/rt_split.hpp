@@ -70,6 +70,9 @@ RT_D void src_gen_impl(const Params& P) {
         P.ray_buffer[pi] = rb;
     }
     if (q < (uint32_t)P.np) P.march_out[q] = word;
+    // the march kernel's team counters start from zero
+    if (blockIdx.x == 0)
+        for (int t = threadIdx.x; t < P.n_teams; t += blockDim.x) P.team_counter[t * 16] = 0u;
     flush_counters(P, 0, 0, 0, 0, n_samples, n_dep);
 }
 
@@ -93,45 +96,55 @@ RT_D void src_march_impl(const Params& P) {
     L.idx = 0;
     L.steps_left = 0;
     uint32_t a_q = 0, a_pi = 0, a_word = 0, a_steps0 = 0;
-    float trk_lb = -1.0f;
+    Trk Tk = {-1.0f, -1.0f, 0};
     constexpr bool TRK = KIND == KIND_BOXES || KIND == KIND_GENERIC;
     const bool trk_ok = TRK && P.cull_ok != 0 && P.src_track != 0;
     // the list's first n_heavy entries are the plan's heavy pixels: the waves that work them off track from the start
     const uint32_t n_heavy = (P.order && P.plan) ? P.plan->n_heavy : 0u;
-    // Static dealing of the list, no shared counter (a launch holds ~250 pixels per wave: claims of 64 from one global word
-    // saturate it — 32 k atomics at ~90 per microsecond were a third of a millisecond —, larger claims leave waves without
-    // work): wave h takes the groups of 64 consecutive entries h, h + NW, h + 2 NW, ... — every wave the same cost profile,
-    // its heaviest group first.  h enumerates the oldest blocks of every CU first (as in the pool kernel), so the head of
-    // the list — the launch's longest raycasts — starts at once, one group per SIMD, in the wave the arbiter serves first.
-    const uint32_t NW = gridDim.x * 4u;
-    const uint32_t hm_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
-    const uint32_t hm_b0 = blockIdx.x / hm_cu * hm_cu;
-    const uint32_t hm_nb = hm_b0 + hm_cu <= gridDim.x ? hm_cu : gridDim.x - hm_b0;
-    const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hm_b0 * 4u + (uint32_t)(threadIdx.x >> 6) * hm_nb + (blockIdx.x - hm_b0)));
-    const uint32_t n_groups = (P.total_items + 63u) >> 6;
-    const uint32_t n_g = h < n_groups ? (n_groups - h + NW - 1u) / NW : 0u;      // groups of this wave's sequence
+    // DEALING.  The list is cut into groups of GS consecutive entries; group g belongs to team g % NT (every team the same
+    // cost profile, its heaviest group first) and the waves of a team — the blocks b with b % NT equal: with NT = the CU count,
+    // the blocks resident on one CU — take their team's groups from ONE counter of their own.  Neither of the two simpler
+    // schemes works here: one global counter saturates (a 1080p launch is 32 k claims of 64, ~90 claims per microsecond: a third
+    // of a millisecond), and static shares ignore that the issue arbiter serves the OLDEST wave of a SIMD first — measured: the
+    // eight waves of a SIMD need 1.4 ... 9.8 kcycles per iteration, by age, and the launch ended when the youngest were done.
+    // With a counter per team the fast waves simply take more; 32 waves per counter do not contend.
+    constexpr uint32_t GS = 32;
+    const uint32_t NT = (uint32_t)P.n_teams;
+    const uint32_t team = blockIdx.x % NT;
+    unsigned int* const tc = P.team_counter + team * 16u;                 // one counter per 64 bytes
+    const uint32_t n_groups = (P.total_items + GS - 1u) / GS;
     const int kwait = P.wait_lanes;
 #ifdef RT_DEBUG_PHASE
     const unsigned long long t_wave0 = __builtin_readcyclecounter();
-    unsigned dbg_iters = 0, dbg_iters_seq = 0;
+    unsigned dbg_iters = 0, dbg_iters_seq = 0, dbg_fast_calls = 0, dbg_fast_steps = 0, dbg_fast2_calls = 0, dbg_fast2_steps = 0, dbg_full2 = 0, dbg_trk = 0, dbg_plain = 0, dbg_tail_lanesteps = 0;
     unsigned long long t_seq_done = 0;
     uint32_t a_item = 0;
+    const uint32_t h = (blockIdx.x * 4u + (threadIdx.x >> 6));
 #endif
 
-    // The sequence is static, so it is PREFETCHED two stages ahead (the loads of a refill are a dependent chain — list entry,
-    // then march word and ray — and a wave refills ten times per launch: unhidden, those round trips are as long as the
-    // marching itself).  q_nn = list entries of group k + 2 (in flight), pf_* = words and rays of group k + 1 (in flight),
-    // LDS `cur` = group k, compacted to the entries that need a raycast; refills read LDS only.
-    auto load_q = [&](uint32_t k) -> uint32_t {
-        const uint32_t item = ((k * NW + h) << 6) + (uint32_t)lane;
-        return (k < n_g && item < P.total_items) ? (P.order ? P.order[item] : item) : 0xffffffffu;
+    // Refills read LDS only: the next group is PREFETCHED while the current one is handed out (the loads of a refill are a
+    // dependent chain — claim, list entry, march word and ray — and a wave refills ten times per launch: unhidden, those round
+    // trips are as long as the marching itself).  `claimed` = the team counter's answer for the group after next (in flight),
+    // pf_* = words and rays of the next group (in flight), LDS `cur` = the current group compacted to the entries that need a
+    // raycast.
+    auto claim = [&]() -> uint32_t {
+        uint32_t j = 0;
+        if (lane == 0) j = atomicAdd(tc, 1u);
+        return j;
     };
     uint32_t pf_q = 0xffffffffu, pf_pi = 0, pf_word = MS_NONE;
     float2 pf_a = make_float2(0, 0), pf_b = make_float2(0, 0), pf_c = make_float2(0, 0);      // origin.xy, (origin.z, direction.x), direction.yz
-    auto load_ray = [&](uint32_t q) {
-        pf_q = q;
+    uint32_t pf_g = 0xffffffffu, cur_g = 0xffffffffu;      // group numbers (wave-uniform); ~0 = none
+    bool more = true;                                      // the team's counter may still hand out groups
+    // fetch group number `g` into pf (g = ~0: empty)
+    auto load_group = [&](uint32_t g) {
+        pf_g = g;
+        pf_q = 0xffffffffu;
         pf_word = MS_NONE;
-        if (q != 0xffffffffu) {
+        const uint32_t item = g * GS + (uint32_t)lane;
+        if (g != 0xffffffffu && (uint32_t)lane < GS && item < P.total_items) {
+            const uint32_t q = P.order ? P.order[item] : item;
+            pf_q = q;
             int px, py;
             pixel_of(P, q, px, py);
             pf_pi = (uint32_t)px * (uint32_t)P.cfg.height + (uint32_t)py;
@@ -142,11 +155,21 @@ RT_D void src_march_impl(const Params& P) {
             pf_c = r[2];
         }
     };
-    uint32_t k_cur = 0, n_cur = 0, c_cur = 0;      // group in `cur`, its entries, entries handed out
-    uint32_t q_nn = load_q(1);
-    load_ray(load_q(0));
-    auto advance_group = [&](bool first) {
-        // pf (group k_cur + 1, or group 0 at the start) -> LDS, compacted; then start the next two loads
+    auto group_of = [&](uint32_t claimed_v) -> uint32_t {
+        const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)claimed_v);
+        const uint32_t g = j * NT + team;
+        return g < n_groups ? g : 0xffffffffu;
+    };
+    uint32_t n_cur = 0, c_cur = 0;      // entries of the group in `cur`, entries handed out
+    uint32_t claimed = claim();
+    {
+        const uint32_t g0 = group_of(claimed);
+        more = g0 != 0xffffffffu;
+        load_group(g0);
+        claimed = more ? claim() : 0u;
+    }
+    auto advance_group = [&]() {
+        // pf -> LDS, compacted; then start the next load and the claim after it
         const bool keep = (pf_word & 3u) == MS_MARCH;
         const unsigned long long km = __ballot(keep);
         if (keep) {
@@ -161,17 +184,22 @@ RT_D void src_march_impl(const Params& P) {
             cur[E_DY][r] = __builtin_bit_cast(uint32_t, pf_c.x);
             cur[E_DZ][r] = __builtin_bit_cast(uint32_t, pf_c.y);
 #ifdef RT_DEBUG_PHASE
-            cur[E_ITEM][r] = (((first ? 0u : k_cur + 1u) * NW + h) << 6) + (uint32_t)lane;
+            cur[E_ITEM][r] = pf_g * GS + (uint32_t)lane;
 #endif
         }
         lds_wave_fence();
         n_cur = (uint32_t)__popcll(km);
         c_cur = 0;
-        if (!first) k_cur++;
-        load_ray(q_nn);
-        q_nn = load_q(k_cur + 2u);
+        cur_g = pf_g;
+        uint32_t g = 0xffffffffu;
+        if (more) {
+            g = group_of(claimed);
+            more = g != 0xffffffffu;
+        }
+        load_group(g);
+        if (more) claimed = claim();
     };
-    advance_group(true);
+    advance_group();
 
     for (;;) {
         // ================================================================ retire finished raycasts, refill the lanes
@@ -205,8 +233,8 @@ RT_D void src_march_impl(const Params& P) {
                 const unsigned long long wm = __ballot(want);
                 if (wm == 0ull) break;
                 if (c_cur == n_cur) {
-                    if (k_cur + 1u >= n_g) break;          // the sequence is exhausted
-                    advance_group(false);
+                    if (pf_g == 0xffffffffu) break;        // the team's list is exhausted
+                    advance_group();
                     continue;
                 }
                 const uint32_t r = (uint32_t)wave_rank(wm);
@@ -230,14 +258,14 @@ RT_D void src_march_impl(const Params& P) {
                     L.steps_left = P.cfg.max_raymarch;
                     L.state = ST_MARCH;
                     L.n_raycasts++;
-                    trk_lb = -1.0f;
+                    Tk.lb2 = Tk.lb3 = -1.0f;
                 }
                 const uint32_t need = (uint32_t)__popcll(wm);
                 c_cur += need < avail ? need : avail;
                 lds_wave_fence();        // (the entries are read before a later advance_group overwrites them)
             }
         }
-        const bool seq_done = c_cur == n_cur && k_cur + 1u >= n_g;
+        const bool seq_done = c_cur == n_cur && pf_g == 0xffffffffu;
 #ifdef RT_DEBUG_PHASE
         if (seq_done && t_seq_done == 0) { t_seq_done = __builtin_readcyclecounter(); dbg_iters_seq = dbg_iters; }
 #endif
@@ -253,23 +281,22 @@ RT_D void src_march_impl(const Params& P) {
         const int cap = n_active >> 2 > 1 ? n_active >> 2 : 1;
         const int kstar = (seq_done && kwait > cap) ? cap : kwait;
         bool tracked = false;
-        if constexpr (TRK) tracked = trk_ok && (((k_cur * NW + h) << 6) <= n_heavy + 64u || n_march <= P.sparse_lanes);
+        if constexpr (TRK) tracked = trk_ok && ((cur_g != 0xffffffffu && cur_g * GS <= n_heavy + GS) || n_march <= P.sparse_lanes);
         if (tracked) {
             if constexpr (TRK) {
                 do {
-                    const bool marching = L.state == ST_MARCH;
-                    const bool can = marching && trk_lb > 0.0f;
-                    const int n_can = __popcll(__ballot(can));
-                    bool fast = false;
-                    int k0 = 0;
-                    if (n_can == n_march) {      // do all of them track the same object?
-                        k0 = __builtin_amdgcn_readlane(L.idx, (int)__builtin_ctzll(__ballot(marching)));
-                        fast = __ballot(marching && L.idx != k0) == 0ull;
-                    }
-                    if (fast) march_fast_src<KIND, NOBJ, SIG>(P, L, trk_lb, k0, 1 << 20);
-                    else if (n_can > 0 && n_march - n_can < 1 + (n_can >> 2)) march_step_src_tracked<KIND, NOBJ, SIG>(P, L, trk_lb, can);
-                    else if (marching) march_step_src_full2<KIND, NOBJ, SIG>(P, L, trk_lb);
 #ifdef RT_DEBUG_PHASE
+                    const uint32_t steps_before = L.n_steps;
+#endif
+                    int it = 1;
+                    const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 1 << 20, it);
+                    (void)form;
+#ifdef RT_DEBUG_PHASE
+                    if (form == 1) { dbg_fast_calls++; dbg_fast_steps += (unsigned)it; }
+                    else if (form == 2) { dbg_fast2_calls++; dbg_fast2_steps += (unsigned)it; }
+                    else if (form == 3) dbg_trk++;
+                    else dbg_full2++;
+                    if (t_seq_done) dbg_tail_lanesteps += wave_sum(L.n_steps - steps_before);
                     dbg_iters++;
 #endif
                     n_march = __popcll(__ballot(L.state == ST_MARCH));
@@ -280,19 +307,25 @@ RT_D void src_march_impl(const Params& P) {
                 if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
 #ifdef RT_DEBUG_PHASE
                 dbg_iters++;
+                dbg_plain++;
+                if (t_seq_done) dbg_tail_lanesteps += (unsigned)n_march;
 #endif
                 n_march = __popcll(__ballot(L.state == ST_MARCH));
             } while (n_march > 0 && (n_active - n_march) < kstar);
-            trk_lb = -1.0f;     // the plain steps did not maintain the bounds
+            Tk.lb2 = Tk.lb3 = -1.0f;     // the plain steps did not maintain the bounds
         }
     }
 #ifdef RT_DEBUG_PHASE
     if (lane == 0) {   // per-wave timeline, written over diff_buffer (unused without adaptive sampling; the host reads it back)
-        unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 4u;
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 8u;
         w[0] = t_wave0;
         w[1] = t_seq_done;
         w[2] = __builtin_readcyclecounter();
         w[3] = (unsigned long long)dbg_iters | ((unsigned long long)dbg_iters_seq << 32);
+        w[4] = (unsigned long long)dbg_fast_calls | ((unsigned long long)dbg_fast_steps << 32);
+        w[5] = (unsigned long long)dbg_full2 | ((unsigned long long)dbg_trk << 32);
+        w[6] = (unsigned long long)dbg_plain | ((unsigned long long)dbg_tail_lanesteps << 32);
+        w[7] = (unsigned long long)dbg_fast2_calls | ((unsigned long long)dbg_fast2_steps << 32);
     }
 #endif
     flush_counters(P, L.n_steps, L.n_raycasts, 0, 0, 0, 0);

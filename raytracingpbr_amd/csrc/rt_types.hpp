@@ -193,6 +193,8 @@ struct Params {
     // src/ pool kernel, cost-ordered ownership (rt_plan.hpp): march steps per local pixel since the last plan (accumulated at
     // write-back), the local pixels ordered by that cost (heaviest first; nullptr = no plan yet: identity), and the plan
     uint32_t* cost_buffer;
+    unsigned int* team_counter;   // split march kernel: one claim counter per team of blocks, 64 bytes apart (zeroed by src_gen)
+    int32_t n_teams;
     uint32_t* march_out;    // wavefront split of the src/ form (rt_split.hpp): one word per local pixel between its three kernels
     const uint32_t* order;
     struct PlanBuf* plan;

@@ -24,7 +24,7 @@ for i in range(4):
                       "longest_wave_kcycles": d[15] >> 10, "iterations_of_busiest_wave": d[7], "plan_heavy": r.counter("plan_heavy"),
                       "raycasts>128_by_list_position(<1k,2k,4k,..)": [x & 0xffffffff for x in d[16:32]], "raycasts>256_by_list_position": [x >> 32 for x in d[16:32]]}), flush=True)
 import numpy as np
-db = np.ascontiguousarray(r.diff_buffer).view(np.uint64).reshape(-1)[:8192 * 4].reshape(-1, 4)
+db = np.ascontiguousarray(r.diff_buffer).view(np.uint64).reshape(-1)[:8192 * 8].reshape(-1, 8)
 db = db[db[:, 0] > 0]
 t0 = db[:, 0].min()
 seq = (db[:, 1] - t0) / 1e3; end = (db[:, 2] - t0) / 1e3; start = (db[:, 0] - t0) / 1e3
@@ -37,5 +37,6 @@ life = (db[:, 2] - db[:, 0]) / 1e3
 top = np.argsort(-life)[:12]
 print(json.dumps({"life_kcycles_pctl": q(life), "bulk_kcycles_pctl(start..sequence_done)": q(seq - start),
                   "slowest_waves": [{"life": round(float(life[i]), 1), "bulk": round(float(seq[i] - start[i]), 1), "iters": int(it[i]), "iters_bulk": int(its[i]),
-                                     "kcycles_per_bulk_iter": round(float((seq[i] - start[i]) / max(1, its[i])), 2), "kcycles_per_tail_iter": round(float((end[i] - seq[i]) / max(1, it[i] - its[i])), 2)} for i in top]}))
+                                     "kcycles_per_bulk_iter": round(float((seq[i] - start[i]) / max(1, its[i])), 2), "kcycles_per_tail_iter": round(float((end[i] - seq[i]) / max(1, it[i] - its[i])), 2),
+                                     "fast_calls": int(db[i, 4] & 0xffffffff), "fast_steps": int(db[i, 4] >> 32), "fast2_calls": int(db[i, 7] & 0xffffffff), "fast2_steps": int(db[i, 7] >> 32), "full2": int(db[i, 5] & 0xffffffff), "tracked": int(db[i, 5] >> 32), "plain": int(db[i, 6] & 0xffffffff), "tail_lanesteps": int(db[i, 6] >> 32)} for i in top]}))
 r.close()
