@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--collective-at-1", action="store_true", help="with --gpus 1: still set up a (1-rank) RCCL communicator and run the gather every step")
     ap.add_argument("--same-device", action="store_true", help="functional test: all ranks share GPU 0 (--transport host, or --transport rccl with RTPBR_RCCL_LIB "
                                                                 "pointing at tests/stubs/libfake_rccl.so: RCCL itself refuses two ranks on one device)")
-    ap.add_argument("--check-gather", action="store_true", help="N > 1: rank 0 also renders the frame untiled and reports whether the gathered frame equals it bit for bit")
+    ap.add_argument("--check-gather", action="store_true", help="(the default for N > 1) rank 0 also renders the frame untiled, OUTSIDE the timed region, and reports whether the gathered frame equals it bit for bit")
+    ap.add_argument("--no-check-gather", action="store_true", help="N > 1: skip the untiled reference render")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     a = ap.parse_args()
     if a.backend == "gloo":
@@ -213,8 +214,9 @@ def side_config(name, a, device, rank0_of=1):
         # L2 < 1e-3 against the oracle by tests/test_gpu_fast.py; the headline stays the exact kernels
         r.set_option("precision", 1)
     if name == "c3_valu":
-        # north_star: "no MFMA".  The same network on the vector ALU only (scheduler-0 kernel), beside the default instance
-        # whose hidden layers run as f32 MFMA (bit-identical results; same FP32 peak rate): the A/B that backs the choice
+        # north_star: "no MFMA".  The same network on the vector ALU only — SAME kernel (LDS ray pool, half-pass policy, baked
+        # configuration), only the 8 MFMAs per layer replaced by fma chains — beside the default instance whose hidden layers
+        # run as f32 MFMA (bit-identical results; same FP32 peak rate): the A/B that backs the choice
         r.set_option("mlp_mfma", 0)
     one_step_launches = name_ == "src_1step"      # the way the reference calls it: ONE bounce-step per pathtrace() launch (src/renderer.py:29-30)
     W, H = wl.cfg.width, wl.cfg.height
@@ -250,9 +252,8 @@ def side_config(name, a, device, rank0_of=1):
            "run_time_kernels": bool(r.counter("jit_active"))}
     if wl.family == "bunny":
         out["mlp_evaluations_per_unit"] = round(r.counter("mlp_lane_evals") / max(c.samples, 1), 2)
-    if name == "c3_valu":       # the vector-ALU kernel does not count network evaluations: no FLOP model for this entry, compare `value` with c3
-        for k in ("algorithmic_flop_per_unit", "achieved_tflops", "frac", "mlp_evaluations_per_unit"):
-            out[k] = None
+    if name == "c3_valu":
+        out["differs_from_c3_in"] = "mlp_mfma only (same pool kernel, same pass policy, same run-time instance)"
     r.close()
     return out
 
@@ -392,7 +393,7 @@ def main():
         dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms_per_step": round(render_ms / a.steps, 3),
                                           "gather_ms_per_step": round(sum(gather_ms[-a.steps:]) / a.steps, 3), "wall_s": round(m["dt"], 4)})
         multi["per_rank"] = per_rank
-        if a.check_gather and rank == 0:
+        if not a.no_check_gather and rank == 0:
             import numpy as np
             # the same sequence of steps, untiled (sample indices advance from step to step; the src/ form also keeps ray state)
             full = make_renderer(wl, local_rank, a, jit=not a.no_jit)
@@ -432,7 +433,10 @@ def main():
         except Exception:
             pass
         if wl.family == "src":
-            res = 32        # option "residency": bounce-steps between two T6 round trips of a pixel (multi-pass walk)
+            res = 32        # option "residency" (library default 32): bounce-steps between two T6 round trips of a pixel (multi-pass walk)
+            for kv in a.opt:
+                if kv.startswith("residency="):
+                    res = int(kv.split("=")[1])
             impl_bytes = int(80 * W * H * max(1, SPP // res) + 32 * c.deposits + 16 * c.sky_lookups)
         else:
             split_on = m["primary_launches"] > 0
@@ -483,6 +487,8 @@ def main():
                     # 12 B per sample (pool kernel W, accumulate R) and 8 B of primary record per sample (primary kernel W, pool
                     # kernel R) and read-modify-writes T7 once per pixel and launch; the src/ form moves T6 (40 B R + W) per pixel
                     # and residency, T7 (16 B R + W) per deposit and 16 B per sky lookup
+                    "implementation_kind": "a MODEL from this run's own counts (records x bytes), not a counter measurement; the src/ form's figure assumes "
+                                           "one T6 round trip per pixel and residency, which over-counts waves that keep their pixels resident",
                     "implementation_bytes_per_step": impl_bytes, "implementation_gbs": round(impl_bytes / max(dt / a.steps, 1e-9) / 1e9, 2),
                     "implementation_frac": round(impl_bytes / max(dt / a.steps, 1e-9) / 1e9 / HBM_PEAK_GBS, 5)},
         }

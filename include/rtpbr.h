@@ -329,7 +329,8 @@ int rtpbr_last_primary_ms(rtpbr_ctx* ctx, float* primary_ms, int* launches);
 int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
 /* Tuning knobs that do not change results.  Keys: "staging_bytes" (sub-launch staging budget),
  * "scheduler" (-1 auto, 0 in-register refill / lock-step, 1 per-wave LDS ray pool),
- * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes", "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
+ * "wait_lanes" (scheduler 0), "shade_lanes", "swap_lanes" (0 = automatic, the default: 8 in the complete-path pool kernel, 12 in the
+ * persistent-ray one), "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
  * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
  * "src_split" (persistent-ray form: a launch of at most this many bounce-steps runs as a wavefront split — per step one

@@ -374,7 +374,7 @@ static RtJitKey make_jit_key(int kind, int n_obj, const ObjM* objm, const rtpbr_
         memcpy(&key.extra[1], &P.box_four_rho, 4);
         memcpy(&key.extra[2], &P.box_rho2m, 4);
         memcpy(&key.extra[3], &P.box_4rho2m, 4);
-        const int ints[7] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes};
+        const int ints[8] = {P.tile_w, P.tile_h, P.ntx, P.nty, P.world, P.shade_lanes, P.swap_lanes, P.mlp_mfma};
         memcpy(key.ints, ints, sizeof ints);
         if (key.baked == 2) memcpy(key.cam_words, &P.cam, sizeof key.cam_words);
     }
@@ -639,7 +639,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
     rt_jit_release(c->jit_mod);
     c->jit_mod = nullptr;
-    const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1 && c->mlp_mfma;   // configuration baking only
+    const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1;   // configuration baking only (incl. which units run the network)
     const bool persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
     if (c->jit != 0 && (persistent || P.scheduler == 1) && c->n_obj <= 8 && (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || (jit_bunny && !persistent))) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
@@ -663,7 +663,6 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                                   "sources on this machine, option jit != 0, a scene of <= 8 analytic shapes (or the neural shape with jit_bake = 1, jit >= 1) "
                                   "and the pool scheduler");
     pack_objects(c, P);
-    if (c->kind == KIND_BUNNY && !c->mlp_mfma) P.scheduler = 0;   // VALU-only MLP lives in the scheduler-0 kernel
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
@@ -1191,7 +1190,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 1 || value > 65) return fail(RTPBR_EINVAL, "mlp_full must be 1..65 (65 = never compute both halves at once)");
         c->mlp_full = (int)value;
     } else if (!strcmp(key, "swap_lanes")) {
-        if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 1..64");
+        if (value < 0 || value > 64) return fail(RTPBR_EINVAL, "swap_lanes must be 0 (automatic: 8 in the complete-path pool kernel, 12 in the src/ one) .. 64");
         c->swap_lanes = (int)value;
     } else if (!strcmp(key, "scheduler")) {
         if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "scheduler must be -1 (auto), 0 or 1");

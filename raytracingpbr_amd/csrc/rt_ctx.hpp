@@ -44,7 +44,7 @@ struct RtJitKey {
     const unsigned* table;      // n_obj x 16 words (ObjM blocks)
     unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed
     unsigned extra[4];          // box_lazy, box_four_rho, box_rho2m, box_4rho2m (bit patterns)
-    int ints[7];                // tile_w, tile_h, ntx, nty, world, shade_lanes, swap_lanes
+    int ints[8];                // tile_w, tile_h, ntx, nty, world, shade_lanes, swap_lanes, mlp_mfma
     unsigned cam_words[21];     // baked == 2: the camera frame (rt::CamFrame) as well — fixed-camera offline renders
 };
 struct RtJitModule {

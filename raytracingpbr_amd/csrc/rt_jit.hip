@@ -207,7 +207,7 @@ static uint64_t baked_hash(const RtJitKey& key) {
     for (int i = 0; i < key.n_obj * 16; i++) th = (th ^ key.table[i]) * 1099511628211ull;
     for (size_t k = 0; k < sizeof(rtpbr_config) / 4; k++) th = (th ^ key.cfg_words[k]) * 1099511628211ull;
     for (int k = 0; k < 4; k++) th = (th ^ key.extra[k]) * 1099511628211ull;
-    for (int k = 0; k < 7; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
+    for (int k = 0; k < 8; k++) th = (th ^ (unsigned)key.ints[k]) * 1099511628211ull;
     if (key.baked == 2)
         for (int k = 0; k < 21; k++) th = (th ^ key.cam_words[k]) * 1099511628211ull + 2;
     return th;
@@ -293,10 +293,10 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
                    "b_.seed = (Q).cfg.seed; b_.frame = (Q).cfg.frame; (Q).cfg = b_; (Q).n_obj = %d; "
                    "(Q).box_lazy = %d; (Q).box_four_rho = __builtin_bit_cast(float, 0x%08xu); (Q).box_rho2m = __builtin_bit_cast(float, 0x%08xu); "
                    "(Q).box_4rho2m = __builtin_bit_cast(float, 0x%08xu); "
-                   "(Q).tile_w = %d; (Q).tile_h = %d; (Q).ntx = %d; (Q).nty = %d; (Q).world = %d; (Q).shade_lanes = %d; (Q).swap_lanes = %d; "
+                   "(Q).tile_w = %d; (Q).tile_h = %d; (Q).ntx = %d; (Q).nty = %d; (Q).world = %d; (Q).shade_lanes = %d; (Q).swap_lanes = %d; (Q).mlp_mfma = %d; "
                    "} while (0)\n",
                 key.n_obj, key.extra[0], key.extra[1], key.extra[2], key.extra[3], key.ints[0], key.ints[1], key.ints[2], key.ints[3],
-                key.ints[4], key.ints[5], key.ints[6]);
+                key.ints[4], key.ints[5], key.ints[6], key.ints[7]);
         fclose(f);
         table_def = "-DRT_JIT_TABLE_FILE=\"" + tfile + "\"";
     }

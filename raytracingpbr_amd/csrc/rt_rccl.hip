@@ -172,23 +172,32 @@ int rt_rccl_check_async(rtpbr_ctx* c) {
         return rt_fail(RTPBR_EHIP, "RCCL asynchronous error on this rank: %s", g_rccl.GetErrorString(async));
     return RTPBR_OK;
 }
-// a communicator whose collective could not be enqueued is unusable (the other ranks may be waiting inside it): abort it
-// so that nothing hangs in a later call, the caller sets up a new one (rtpbr_rccl_init) after handling the error
+// A communicator whose COLLECTIVE could not be enqueued is unusable (the other ranks may be waiting inside it): it is
+// aborted (ncclCommAbort) so that nothing hangs in a later call, and the context forgets it — the caller handles the error
+// and sets up a new one (rtpbr_rccl_init / rtpbr_rccl_init_all) before the next gather.  A librccl without ncclCommAbort gets
+// no ncclCommDestroy in its place: destroying a communicator whose peers sit in a half-enqueued collective can itself hang —
+// the handle is leaked instead.  Purely LOCAL failures before the collective (hipSetDevice, the pack launch) leave the
+// communicator alone: nobody is waiting yet.
 static void abort_comm(rtpbr_ctx* c) {
     if (!c->comm) return;
     if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c->comm);
-    else (void)g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
 }
 
-// pack -> ncclGather -> (root) unpack, all on the context's stream
-static int enqueue_gather(rtpbr_ctx* c) {
+// pack -> ncclGather -> (root) unpack, all on the context's stream.  *collective_failed: the failure happened at (or after)
+// the ncclGather call.
+static int enqueue_gather(rtpbr_ctx* c, bool* collective_failed) {
+    *collective_failed = false;
     RT_HIP_TRY(hipSetDevice(c->device));
     c->P.cfg = c->cfg;
     c->P.image_buffer = c->image_buffer;
     launch_pack(c->P, (float4*)c->gather_send, c->stream);
     RT_HIP_TRY(hipGetLastError());
+    *collective_failed = true;
     NCCL_TRY(g_rccl.Gather(c->gather_send, c->gather_recv, (size_t)c->P.np * 4, ncclFloat, 0, (ncclComm_t)c->comm, c->stream));
+    *collective_failed = false;
     return RTPBR_OK;
 }
 static int enqueue_unpack(rtpbr_ctx* c) {
@@ -209,8 +218,9 @@ extern "C" int rtpbr_gather_tiles(rtpbr_ctx* c) {
     if (int r = check_comm(c)) return r;
     RT_HIP_TRY(hipSetDevice(c->device));
     if (int r = ensure_gather_buffers(c)) return r;
-    if (int r = enqueue_gather(c)) {
-        abort_comm(c);
+    bool collective_failed = false;
+    if (int r = enqueue_gather(c, &collective_failed)) {
+        if (collective_failed) abort_comm(c);
         return r;
     }
     if (int r = enqueue_unpack(c)) return r;
@@ -226,7 +236,8 @@ extern "C" int rtpbr_gather_tiles_all(rtpbr_ctx** ctxs, int n) {
     }
     NCCL_TRY(g_rccl.GroupStart());
     int rc = RTPBR_OK;
-    for (int i = 0; i < n && rc == RTPBR_OK; i++) rc = enqueue_gather(ctxs[i]);
+    bool collective_failed = false;     // (inside a group every member that WAS enqueued waits for the others: any failure aborts all)
+    for (int i = 0; i < n && rc == RTPBR_OK; i++) rc = enqueue_gather(ctxs[i], &collective_failed);
     const ncclResult_t ge = g_rccl.GroupEnd();        // the group is always closed, whatever happened inside it
     if (rc != RTPBR_OK || ge != ncclSuccess) {
         // a member could not be enqueued (or the group could not be launched): the ranks that were are waiting for it —

@@ -578,7 +578,8 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     vec3 nrm = mk(0, 0, 0);
                     if (__any(st == SL_HIT)) {
                         w_mlp_lane += 4u * (uint32_t)__popcll(__ballot(st == SL_HIT));
-                        nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, tbl_w, lane, st == SL_HIT, hp, w_mlp_wave);
+                        if (P.mlp_mfma) nrm = bunny_normal_wave(P, b_frag, b_lds, b_bias, tbl_w, lane, st == SL_HIT, hp, w_mlp_wave);
+                        else if (st == SL_HIT) nrm = calc_normal<KIND_BUNNY>(P, lds_obj[0], hp);
                     }
                     if (st == SL_HIT) {
                         alive = shade_hit<KIND, true>(P, lds_obj, R, nrm);
@@ -718,7 +719,11 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                         const bool sel = b_pending && rank >= first && rank < first + take;
                         w_mlp_wave += (uint32_t)halves;
                         w_mlp_lane += (uint32_t)take;
-                        const float sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp, sel ? rank - first : -1, halves);
+                        // (option mlp_mfma = 0: the same network on the vector ALU, per lane, under the same pass policy — the A/B
+                        // that isolates the matrix cores; the chain order is the same, so are the bits)
+                        float sd;
+                        if (P.mlp_mfma) sd = bunny_mlp_wave(b_frag, P.bunny, b_lds, b_bias, lane, b_lp, sel ? rank - first : -1, halves);
+                        else sd = sel ? bunny_mlp(P.bunny, b_lp) : 0.0f;
                         if (sel) {
                             march_update(P, L, 0, bunny_post_value(P, sd));
                             b_pending = false;

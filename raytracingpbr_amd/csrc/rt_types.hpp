@@ -107,7 +107,7 @@ struct Counters {
     unsigned long long samples, raycasts, march_steps, hits, sky_lookups, deposits;
     // neural SDF (matrix-core path): MLP passes over a wave, and the ray-evaluations those passes were needed for
     unsigned long long mlp_wave_evals, mlp_lane_evals;
-    // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; "dbg0".."dbgf"
+    // instrumented builds only (-DRT_DEBUG_PHASE through RTPBR_JIT_EXTRA_FLAGS): cycles per phase, passes, lanes; counters "dbg0".."dbg9", "dbga".."dbgv"
     unsigned long long dbg[32];
     // The six work counters are ADDED UP here by the kernels: 64 shards of one cache line each, shard = blockIdx % 64, word k =
     // march_steps, raycasts, hits, sky_lookups, samples, deposits (flush_counters).  One word per counter saturates at ~90

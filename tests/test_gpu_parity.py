@@ -181,7 +181,8 @@ def test_neural_sdf_pass_policy_independence():
     assert evals > 0
     for opts in ({}, {"mlp_lanes": 1, "mlp_full": 1}, {"mlp_lanes": 1, "mlp_full": 65}, {"mlp_lanes": 64, "mlp_full": 64},
                  {"mlp_lanes": 33, "mlp_full": 34}, {"mlp_lanes": 16, "mlp_full": 48, "shade_lanes": 5, "swap_lanes": 3},
-                 {"mlp_lanes": 40, "mlp_full": 60, "waves_per_cu": 4}, {"mlp_mfma": 0}, {"jit": 2, "jit_bake": 1, "mlp_lanes": 7}):
+                 {"mlp_lanes": 40, "mlp_full": 60, "waves_per_cu": 4}, {"mlp_mfma": 0}, {"jit": 2, "jit_bake": 1, "mlp_lanes": 7},
+                 {"mlp_mfma": 0, "jit": 2, "jit_bake": 1}, {"mlp_mfma": 0, "mlp_lanes": 9, "mlp_full": 33}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
@@ -582,6 +583,20 @@ def test_bench_scale_command_with_one_process_per_rank(workload, nproc):
     assert all(p["kernel_ms_per_step"] > 0 and p["gather_ms_per_step"] > 0 for p in mg["per_rank"])
 
 
+def test_real_rccl_two_ranks_when_two_devices():
+    """First contact with a multi-GPU node checks itself: when this box has >= 2 devices, the SCALE command with N = 2 runs on
+    REAL RCCL (no stub) — ncclCommInitRank with two ranks, ncclGather over the fabric, the abort path armed — and the line must
+    say so: two ranks, and the gathered frame equal to the untiled one bit for bit (bench.py checks that by default for N > 1).
+    Skipped on a one-GPU box (there the stub-backed test above covers everything but RCCL itself)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    j = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "480", "--height", "270", "--spp", "16", "--no-cpu-baseline"], nproc=2)
+    mg = j["multi_gpu"]
+    assert j["n_gpus"] == 2 and mg["rccl_nranks"] == 2 and mg["rccl_version"] > 20000
+    assert mg["gathered_equals_untiled"] is True
+
+
 def test_bench_default_transport_is_the_c_abi_rccl_gather():
     """The transport a SCALE run takes by default — rtpbr_rccl_unique_id / rccl_init / gather_tiles, i.e. ROCm's librccl
     behind the C ABI — driven by bench.py itself on this box's one GPU (a 1-rank communicator): RCCL reports the rank
@@ -636,7 +651,12 @@ def test_fuzz_random_scenes_match_oracle(seed):
         # and in the run-time compiled instance
         for opts in ({"plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "tiny_own": 2, "jit": 0},
                      {"plan_interval": 1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "heavy_own": 3, "tiny_waves": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": seed % 2},
-                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1}):
+                     {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1},
+                     # the wavefront split of every bounce-step (round 5, rt_split.hpp) with its two-bound tracked march — one- and
+                     # two-object lean loops on whatever shapes the fuzzer made, every pixel with a recorded cost on the heavy head —
+                     # and with the one-bound march of round 4
+                     {"src_split": 256, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "jit": seed % 2, "jit_bake": 1},
+                     {"src_split": 256, "src_track": 1, "split_wait": 5, "jit": 1 - seed % 2}):
             g = Renderer(sc, cfg)
             for k, v in opts.items():
                 g.set_option(k, v)
