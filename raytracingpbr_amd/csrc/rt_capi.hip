@@ -549,8 +549,9 @@ static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
     *cap = need;
     return RTPBR_OK;
 }
-static int ensure_staging(rtpbr_ctx* c, size_t items, bool split) {
-    if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(StageRec))) return r;
+static int ensure_staging(rtpbr_ctx* c, size_t items, bool split, bool stage = true) {
+    if (stage)
+        if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(StageRec))) return r;
     if (split)
         if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * sizeof(float2))) return r;
     return RTPBR_OK;
@@ -811,7 +812,10 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         int left = n;
         while (left > 0) {
             const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
-            long long per_spp = (long long)P.np * (long long)(sizeof(StageRec) + (split_ok ? sizeof(float2) : 0));
+            // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
+            const bool unstaged = c->precision != 0 && c->jit_mod != nullptr && P.scheduler == 1;
+            long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
+            if (per_spp < 1) per_spp = 1;
             long long kmax = c->staging_bytes / per_spp;
             if (kmax < 1) kmax = 1;
             // keep total_items within 32 bits
@@ -822,7 +826,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             int K = (int)(left < kmax ? left : kmax);
             // the extra launch has a fixed cost of ~0.3 ms: below ~8 M items the fused kernel is faster
             const bool split = split_ok && (c->primary_split == 2 || (long long)P.np * K >= (1LL << 23));
-            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split)) {
+            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split, !unstaged)) {
                 // no room for K samples per launch: halve the budget and go round again (1 spp per launch must fit)
                 if (r != RTPBR_ENOMEM || K == 1)
                     return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "no device memory for the staging of one sample per pixel") : r;
@@ -868,7 +872,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             } else
                 launch_trace(P, c->kind, grid, c->stream);
             HIP_TRY(hipEventRecord(b, c->stream));
-            launch_accumulate(P, c->stream);
+            if (!unstaged) launch_accumulate(P, c->stream);
             c->sample_base += (uint32_t)K;
             left -= K;
         }
@@ -1204,14 +1208,16 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 1) return fail(RTPBR_EINVAL, "reserve_spp must be >= 1");
         if (int r = set_dev(c)) return r;
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
-        long long per_spp = (long long)c->P.np * (long long)(sizeof(StageRec) + (split_ok ? sizeof(float2) : 0));
+        const bool unstaged = c->precision != 0 && c->scheduler != 0;      // the tolerance flavour has no staging (rtpbr_sample)
+        long long per_spp = (long long)c->P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
+        if (per_spp < 1) per_spp = 1;
         long long kmax = c->staging_bytes / per_spp;
         long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)c->P.np;
         if (k32 < 1) k32 = 1;
         if (kmax > k32) kmax = k32;
         if (kmax < 1) kmax = 1;
         const long long K = value < kmax ? value : kmax;
-        if (int r = ensure_staging(c, (size_t)c->P.np * (size_t)K, split_ok))
+        if (int r = ensure_staging(c, (size_t)c->P.np * (size_t)K, split_ok, !unstaged))
             return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "reserve_spp: no device memory for the staging of that many samples per pixel") : r;
     } else if (!strcmp(key, "sample_base")) {
         c->sample_base = (uint32_t)value;

@@ -315,7 +315,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     if (key.fast) {
         // the tolerance flavour (rt_math.hpp RT_FAST_MATH): contraction allowed, v_rcp-based divide, hardware transcendentals
         argv[5] = "-ffp-contract=fast";
-        argv.insert(argv.begin() + 10, {"-DRT_FAST_MATH=1", "-fno-hip-fp32-correctly-rounded-divide-sqrt"});
+        // (-munsafe-fp-atomics: the f32 adds into image_buffer as hardware atomics, not compare-and-swap loops)
+        argv.insert(argv.begin() + 10, {"-DRT_FAST_MATH=1", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics"});
     }
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     argv.insert(argv.begin() + 10, extra.begin(), extra.end());

@@ -105,6 +105,61 @@ RT_D void write_sample(const Params& P, uint32_t item, vec3 col) {
     reinterpret_cast<StageRec*>(P.stage)[item] = StageRec{col.x, col.y, col.z};
 }
 
+RT_D void lds_wave_fence();
+// TOLERANCE FLAVOUR (RT_FAST_MATH): no staging.  The exact kernels stage one record per sample because image_buffer must be
+// summed in SAMPLE ORDER to stay bit-identical with `image_buffer[i,j] += vec4(color,1)` (samples finish out of order); a
+// flavour that is held to a tolerance needs no order.  Every wave keeps 16 per-pixel accumulators in LDS (direct-mapped by
+// local pixel; a wave's samples in flight belong to a handful of neighbouring pixels: consecutive work items are consecutive
+// samples of one pixel), finished samples are added there with LDS float atomics, and an accumulator goes to image_buffer —
+// four f32 atomics — when its slot is taken by another pixel or the kernel ends: 16 bytes per pixel and wave instead of 24
+// bytes per SAMPLE, and no accumulate kernel.  The order of the additions depends on the schedule: results agree to rounding
+// from run to run, not bit for bit (the flavour promises a tolerance).
+constexpr int ACC_SLOTS = 16;
+struct AccView {
+    float (*acc)[4];       // [slot][r, g, b, count]
+    uint32_t* tag;         // local pixel held by the slot, ~0 = empty
+};
+RT_D void acc_flush_slot(const Params& P, const AccView& A, uint32_t s, uint32_t q, int lane, uint32_t& n_dep) {
+    int px, py;
+    if (pixel_of(P, q, px, py) && lane < 4) {
+        float* dst = reinterpret_cast<float*>(P.image_buffer + ((size_t)px * P.cfg.height + py)) + lane;
+        atomicAdd(dst, A.acc[s][lane]);
+    }
+    if (lane == 0) n_dep += (uint32_t)A.acc[s][3];
+}
+// all lanes call it (wave-uniform control flow); `fin`: this lane holds a finished sample of local pixel q
+RT_D void acc_add(const Params& P, const AccView& A, bool fin, uint32_t q, vec3 col, int lane, uint32_t& n_dep) {
+    unsigned long long m = __ballot(fin);
+    while (m) {
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)__builtin_ctzll(m));
+        const bool mine = fin && q == q0;
+        const uint32_t s = q0 & (uint32_t)(ACC_SLOTS - 1);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.tag[s]);
+        if (t != q0) {
+            if (t != 0xffffffffu) acc_flush_slot(P, A, s, t, lane, n_dep);
+            lds_wave_fence();
+            if (lane < 4) A.acc[s][lane] = 0.0f;
+            if (lane == 0) A.tag[s] = q0;
+            lds_wave_fence();
+        }
+        if (mine) {
+            atomicAdd(&A.acc[s][0], col.x);
+            atomicAdd(&A.acc[s][1], col.y);
+            atomicAdd(&A.acc[s][2], col.z);
+            atomicAdd(&A.acc[s][3], 1.0f);
+        }
+        lds_wave_fence();
+        m &= ~__ballot(mine);
+    }
+}
+RT_D void acc_flush_all(const Params& P, const AccView& A, int lane, uint32_t& n_dep) {
+    lds_wave_fence();
+    for (uint32_t s = 0; s < (uint32_t)ACC_SLOTS; s++) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.tag[s]);
+        if (t != 0xffffffffu) acc_flush_slot(P, A, s, t, lane, n_dep);
+    }
+}
+
 // renderer.py:32-35: jitter, get_ray, color = 1, then roulette at i = 0 (p = 0, the draw is consumed).
 // returns 1 = ray ready to march, 0 = finished already, -1 = padding pixel of an edge tile (nothing to trace)
 RT_D int start_item(const Params& P, PathRay& R) {
@@ -472,10 +527,19 @@ RT_D void trace_paths_pool_impl(const Params& P) {
     // exists: never live together, and 1 KB less per block lets a seventh block fit into a CU's 160 KB
     __shared__ uint32_t tbl_all[PARK ? 1 : 4][64];
     __shared__ uint32_t sstate_all[4][64];
+#if RT_FAST_MATH
+    __shared__ float acc_all[4][ACC_SLOTS][4];
+    __shared__ uint32_t acc_tag_all[4][ACC_SLOTS];
+#endif
     stage_objects(P, lds_obj);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+#if RT_FAST_MATH
+    const AccView A = {acc_all[wave], acc_tag_all[wave]};
+    if (lane < ACC_SLOTS) A.tag[lane] = 0xffffffffu;
+    uint32_t n_dep = 0;
+#endif
     uint32_t (*pool)[64] = pool_all[wave];
     uint32_t* sstate = sstate_all[wave];
     uint32_t* const tbl_w = PARK ? reinterpret_cast<uint32_t*>(&save_all[PARK ? wave : 0][0][0]) : tbl_all[PARK ? 0 : wave];
@@ -588,7 +652,11 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                     }
                 }
                 w_sky += (uint32_t)__popcll(__ballot(sky1 != 0));
+#if RT_FAST_MATH
+                acc_add(P, A, (st == SL_HIT || st == SL_MISS) && !alive, R.item / (uint32_t)P.K, R.col, lane, n_dep);
+#else
                 if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col);
+#endif
                 w_samples += (uint32_t)__popcll(__ballot((st == SL_HIT || st == SL_MISS) && !alive));
                 if (st == SL_HIT || st == SL_MISS) st = SL_EMPTY;
                 // refill free slots with fresh pixel-samples.  start_item costs ~200 instructions and a shading pass frees
@@ -614,9 +682,15 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                         } else {
                             alive = true;
                         }
-                    } else if (r == 0) write_sample(P, R.item, R.col);
+                    }
+#if !RT_FAST_MATH
+                    else if (r == 0) write_sample(P, R.item, R.col);
+#endif
                     roulette0 = r == 0;
                 }
+#if RT_FAST_MATH
+                acc_add(P, A, roulette0, R.item / (uint32_t)P.K, R.col, lane, n_dep);
+#endif
                 w_samples += (uint32_t)__popcll(__ballot(roulette0));
                 if (resumed == ST_HIT || resumed == ST_MISS) {
                     // park the finished primary raycast; it is shaded with the next batch
@@ -795,6 +869,12 @@ RT_D void trace_paths_pool_impl(const Params& P) {
         atomicAdd(&P.counters->mlp_wave_evals, (unsigned long long)w_mlp_wave);
         atomicAdd(&P.counters->mlp_lane_evals, (unsigned long long)w_mlp_lane);
     }
+#if RT_FAST_MATH
+    acc_flush_all(P, A, lane, n_dep);
+    const uint32_t dep_out = n_dep;
+#else
+    const uint32_t dep_out = 0;
+#endif
     // (the neural-SDF march counts its steps per lane: run-ahead lanes step at different times)
     flush_counters(P, KIND == KIND_BUNNY ? L.n_steps : (lane == 0 ? w_steps : 0u), lane == 0 ? w_raycasts : 0u,
 #ifdef RT_DEBUG_PHASE
@@ -802,7 +882,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
 #else
                    lane == 0 ? w_hits : 0u,
 #endif
-                   lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, 0);
+                   lane == 0 ? w_sky : 0u, lane == 0 ? w_samples : 0u, dep_out);
 }
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 __global__ void __launch_bounds__(256, pool_waves(KIND)) trace_paths_pool(const Params P) { trace_paths_pool_impl<KIND, NOBJ, SIG>(P); }
