@@ -137,7 +137,9 @@ def make_renderer(wl, device, a, jit=True, bake=True):
         # configuration (rt_jit.hip: ~1-2 s once, then a disk cache), as Taichi JIT-compiles the reference's kernels; falls
         # back to the ahead-of-time instance if hipcc is not available on the box
         r.set_option("jit", 1)
-        r.set_option("jit_bake", 2 if bake else 0)       # scene, configuration AND the camera frame baked: a fixed-camera offline render
+        # bake: True / 2 = scene, configuration AND the camera frame baked (a fixed-camera offline render), 1 = scene and
+        # configuration only (the camera stays a launch argument: what an interactive host uses), False / 0 = nothing baked
+        r.set_option("jit_bake", 2 if bake is True else int(bake))
     else:
         r.set_option("jit", 0)
     for kv in a.opt:
@@ -506,7 +508,7 @@ def main():
                    "first_use_note": "first rtpbr_sample() of a whole step: hipcc --genco of the scene's kernels into a fresh cache + module load "
                                      "+ first touch of the staging + the step itself" if not a.keep_jit_cache else "first rtpbr_sample() with the user's cache"}
             if not a.no_jit and not a.no_configs:
-                for key, (j, b) in (("unbaked_value", (True, False)), ("aot_value", (False, False))):
+                for key, (j, b) in (("camera_free_value", (True, 1)), ("unbaked_value", (True, False)), ("aot_value", (False, False))):
                     r2 = make_renderer(wl, local_rank, a, jit=j, bake=b)
                     if wl.family != "src":
                         r2.set_option("reserve_spp", SPP)
@@ -515,6 +517,9 @@ def main():
                     m2 = measure(wl, r2, 1, 0)
                     jit[key] = round(W * H * SPP / m2["dt"] / 1e6, 1)
                     r2.close()
+            jit["note"] = ("value (the headline) = run-time instance with scene, configuration and camera frame baked (jit_bake 2: a moved camera "
+                           "recompiles); camera_free_value = scene and configuration baked, camera a launch argument (jit_bake 1); unbaked_value = "
+                           "run-time instance, nothing baked; aot_value = the ahead-of-time library alone (no hipcc on the target)")
             out["jit"] = jit
             if a.workload == "c2" and not a.no_configs:
                 out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c3_valu", "c4", "c5", "src", "src_768", "src_4k", "src_1step",
