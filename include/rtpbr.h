@@ -333,6 +333,10 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * persistent-ray one), "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
  * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
+ * "src_chain" (persistent-ray form, fused launches: 1, default = when the plan finds the launch as long as its heaviest pixel's
+ * dependency chain AND the device has room beside the pool kernel's grid, the heaviest pixels — the chain set — run in the chain
+ * kernel on a second stream, alone or in small groups per wave; 0 = never, 2 = whenever the plan says so), "chain_waves" (the most
+ * waves the chain set may take, default 1024),
  * "src_split" (persistent-ray form: a launch of at most this many bounce-steps runs as a wavefront split — per step one
  * coherent kernel for roulette / deposit / camera ray, one for the raycasts on the cost-ordered pixel list, one for shading —
  * instead of the fused pool kernel; 0 = never, default 1), "split_wait" (its march kernel refills lanes when this many are

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "librtpbr_hip.so")
 SOURCES = ["rt_kernels.hip", "rt_capi.hip", "rt_rccl.hip", "rt_jit.hip"]
-HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", "rt_trace.hpp", "rt_persistent.hpp", "rt_split.hpp", "rt_ctx.hpp", "rt_jit_tu.hip", os.path.join("..", "..", "include", "rtpbr.h")]
+HEADERS = ["rt_math.hpp", "rt_types.hpp", "rt_device.hpp", "rt_trace.hpp", "rt_persistent.hpp", "rt_split.hpp", "rt_chain.hpp", "rt_ctx.hpp", "rt_jit_tu.hip", os.path.join("..", "..", "include", "rtpbr.h")]
 # -ffp-contract=off: only the fmaf written in rt_math.hpp are fused (bit-reproducible results);
 # no -ffast-math: f32 divide and sqrt stay correctly rounded.
 # -fno-slp-vectorize: the SLP vectoriser pairs independent f32 ops of neighbouring boxes into

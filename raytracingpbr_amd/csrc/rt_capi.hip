@@ -97,6 +97,12 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
     if (c->ev_total0) (void)hipEventDestroy(c->ev_total0);
     if (c->ev_total1) (void)hipEventDestroy(c->ev_total1);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RTPBR_OK;
@@ -726,6 +732,11 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 P.age_on = c->age_on;
                 P.age_pack = 0;
                 for (int k = 0; k < 8; k++) P.age_pack |= (uint32_t)(c->age_w[k] & 15) << (4 * k);
+                // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel: only when the device has room for both — the pool
+                // grid leaves at least the chain set's waves free.  (Frames that fill the device, 1280x720 and up, are not
+                // chain-bound; there an extra kernel only takes wave slots from the pool: measured -12 % at 720p.)
+                const bool chain_fits = c->src_chain != 0 && c->grid_blocks == 0 && grid + (c->chain_waves + 3) / 4 <= max_blocks;
+                const bool chain_eff = c->src_chain != 0 && (chain_fits || c->src_chain == 2);
                 if (c->src_plan) {
                     if (c->plan_np != (size_t)P.np) {
                         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -746,7 +757,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                     }
                     if (c->cost_steps >= c->plan_interval) {
                         launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
-                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), c->stream);
+                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), chain_eff ? c->chain_waves : 0, c->stream);
                         c->order_valid = true;
                         c->cost_steps = 0;
                     }
@@ -796,10 +807,33 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                             launch_src_shade(P, c->kind, c->stream);
                         }
                     }
-                } else if (c->jit_mod) {
-                    if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
-                } else
-                    launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+                } else {
+                    // A chain-bound launch (plan_scan decides, on the device) hands the head of the cost-ordered list to the chain
+                    // kernel (rt_chain.hpp), which runs BESIDE the pool kernel on a second stream: forked after the plan, joined
+                    // before anything else touches the buffers.  Its grid covers the largest chain set a plan can make; waves
+                    // without an entry leave at once.
+                    P.chain_on = (chain_eff && P.order) ? 1 : 0;
+                    if (P.chain_on) {
+                        if (!c->stream2) {
+                            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                        }
+                        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+                        const int cgrid = 512;       // 2048 waves: the largest chain set (the plan may be older than this launch's grid)
+                        if (c->jit_mod) {
+                            if (int r = rt_jit_launch_steps(c->jit_mod->chain_steps, P, steps, (unsigned)cgrid, c->stream2)) return r;
+                        } else
+                            launch_chain_steps(P, c->kind, steps, cgrid, c->stream2);
+                        HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+                    }
+                    if (c->jit_mod) {
+                        if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
+                    } else
+                        launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+                    if (P.chain_on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                }
             } else if (c->jit_mod) {
                 if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
             } else
@@ -1112,6 +1146,16 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 128) return fail(RTPBR_EINVAL, "heavy_own must be 0 (no heavy waves) .. 128");
         c->heavy_own = (int)value;
         c->order_valid = false;       // the plan's share of heavy pixels was sized for the old value
+        c->cost_steps = 0;
+    } else if (!strcmp(key, "src_chain")) {
+        if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "src_chain must be 0 (never), 1 (when the device has room beside the pool kernel) or 2 (always: tests)");
+        c->src_chain = (int)value;
+        c->order_valid = false;       // the plan carries the chain set
+        c->cost_steps = 0;
+    } else if (!strcmp(key, "chain_waves")) {
+        if (value < 1 || value > 2048) return fail(RTPBR_EINVAL, "chain_waves must be 1 .. 2048");
+        c->chain_waves = (int)value;
+        c->order_valid = false;
         c->cost_steps = 0;
     } else if (!strcmp(key, "src_split")) {
         if (value < 0 || value > 256) return fail(RTPBR_EINVAL, "src_split must be 0 (never) .. 256 (bounce-steps per launch up to which the wavefront split runs)");

@@ -16,6 +16,7 @@ void launch_accumulate(const Params& P, hipStream_t st);
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
 void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
 int persistent_pool_blocks_per_cu(int kind);
+void launch_chain_steps(const Params& P, int kind, int steps, int grid, hipStream_t st);
 void launch_src_gen(const Params& P, int kind, hipStream_t st);
 void launch_src_march(const Params& P, int kind, int grid, hipStream_t st);
 int src_march_blocks_per_cu(int kind);
@@ -29,7 +30,7 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, int n_cls, hipStream_t st);
+                 int tiny_waves, int n_cu, int n_cls, int chain_on, hipStream_t st);
 }  // namespace rt
 
 // run-time compiled per-scene instances (rt_jit.hip)
@@ -50,6 +51,7 @@ struct RtJitKey {
 struct RtJitModule {
     hipModule_t module = nullptr;
     hipFunction_t trace = nullptr, primary = nullptr, persistent_pool = nullptr, persistent_steps = nullptr;
+    hipFunction_t chain_steps = nullptr;                                           // the chain kernel (rt_chain.hpp)
     hipFunction_t src_gen = nullptr, src_march = nullptr, src_shade = nullptr;      // the wavefront split of one src/ bounce-step (rt_split.hpp)
     int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0, march_blocks_per_cu = 0;
     std::string path;
@@ -139,6 +141,10 @@ struct rtpbr_ctx {
     unsigned int* team_counter = nullptr;   // 1024 counters x 64 bytes (split march kernel)
     uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
     size_t march_np = 0;
+    int src_chain = 1;            // src/ form, fused launches: the plan's chain set runs in the chain kernel beside the pool kernel (rt_chain.hpp)
+    int chain_waves = 1024;       // ... the most waves the chain set may take (<= 2048)
+    hipStream_t stream2 = nullptr;      // ... on this stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int src_split = 1;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never (measured at 1080p: one step 0.51 against 0.60 ms fused; two steps 1.3 against 0.65)
     int split_wait = 24;          // ... its march kernel refills when this many lanes are free
     uint32_t* order = nullptr;         // np x u32

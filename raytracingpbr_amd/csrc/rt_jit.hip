@@ -85,7 +85,7 @@ bool read_file(const std::string& path, std::vector<char>& out) {
 
 // FNV-1a over the sources the translation unit is made of: a changed source invalidates the cache
 bool source_hash(const std::string& dir, uint64_t* h) {
-    const char* files[] = {"rt_jit_tu.hip", "rt_trace.hpp", "rt_persistent.hpp", "rt_split.hpp", "rt_device.hpp", "rt_types.hpp", "rt_math.hpp", "../../include/rtpbr.h"};
+    const char* files[] = {"rt_jit_tu.hip", "rt_trace.hpp", "rt_persistent.hpp", "rt_split.hpp", "rt_chain.hpp", "rt_device.hpp", "rt_types.hpp", "rt_math.hpp", "../../include/rtpbr.h"};
     uint64_t x = 1469598103934665603ull;
     std::vector<char> buf;
     for (const char* f : files) {
@@ -457,6 +457,7 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
         if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_pool, m->module, "rt_jit_persistent_pool");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->persistent_steps, m->module, "rt_jit_persistent_steps");
         if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->persistent_blocks_per_cu, m->persistent_pool, 256, 0);
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->chain_steps, m->module, "rt_jit_chain_steps");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_gen, m->module, "rt_jit_src_gen");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_march, m->module, "rt_jit_src_march");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_shade, m->module, "rt_jit_src_shade");

@@ -63,6 +63,11 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_src_shade(const Params 
     RT_JIT_BAKE_PARAMS(Q);
     src_shade_impl<RT_JIT_KIND>(Q);
 }
+extern "C" __global__ void __launch_bounds__(256) rt_jit_chain_steps(const Params P, int steps) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    chain_steps_impl<RT_JIT_KIND, TU_NOBJ, RT_JIT_SIG>(Q, steps);
+}
 extern "C" __global__ void __launch_bounds__(256) rt_jit_persistent_steps(const Params P, int steps) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);

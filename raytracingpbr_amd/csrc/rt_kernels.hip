@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) plan_hist(const uint32_t* __restrict__ co
 // A pixel is heavy when its own chain of march steps is long against BOTH the frame's mean pixel (mean_x16 / 16 times)
 // and a wave's share of the whole frame in march iterations, total / (64 lanes x waves) (bulk_x16 / 16 times).
 __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uint32_t n_waves, uint32_t heavy_own, uint32_t mean_x16, uint32_t bulk_x16,
-                                                 uint32_t tiny_waves, uint32_t n_cls) {
+                                                 uint32_t tiny_waves, uint32_t n_cls, uint32_t chain_on) {      // chain_on: 0 = no chain set, else the most waves it may take
     __shared__ uint32_t h[256];
     const uint32_t b = threadIdx.x;
     h[b] = plan->hist[b];
@@ -226,6 +226,46 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         const double chain = top ? (double)bucket_floor(top) : 0.0;
         const double bulk = total / (64.0 * (double)(n_waves ? n_waves : 1u));
         plan->tiny_waves = chain > 3.0 * bulk ? n_waves / 4u : (tiny_waves < n_waves / 8u ? tiny_waves : n_waves / 8u);
+        // ---- the chain set (rt_chain.hpp): a launch that is as long as its longest chain hands the head of the list to the chain
+        // kernel.  Waves are packed greedily, heaviest pixel first, by the SUM of their pixels' steps — measured: a chain wave takes
+        // ~800 cycles per lane-step whether it holds one pixel or eight (the raycasts of different pixels hardly overlap: a wave
+        // iterates as long as its longest ray and every iteration pays for the most expensive form any lane needs) — every wave's
+        // sum below the heaviest pixel's own steps (x 1.15); at most 8 pixels per wave, at most 2048 waves / half the grid's;
+        // pixels lighter than an eighth of the heaviest (or not heavy at all) stay in the pool kernel.
+        plan->n_chain = 0;
+        plan->n_chain_waves = 0;
+        plan->chain_start[0] = 0;
+        if (chain_on && chain > 3.0 * bulk && n_heavy > 0u) {
+            const double T = chain * 1.15, thr_c = thr > chain / 8.0 ? thr : chain / 8.0;
+            const uint32_t max_w = chain_on < 2048u ? chain_on : 2048u;
+            uint32_t wv = 0, cnt = 0, pos = 0;
+            double load = 0.0;
+            bool full = false;
+            for (uint32_t j = 255u; j >= 1u && !full; j--) {
+                const double c = (double)bucket_floor(j) * 1.045;        // (a bucket spans 9 %)
+                if (c <= thr_c) break;
+                for (uint32_t i = 0; i < h[j]; i++) {
+                    double add = c;
+                    if (cnt > 0u && (load + add > T || cnt >= 8u)) {
+                        wv++;
+                        plan->chain_start[wv] = pos;          // (closes the previous wave)
+                        if (wv >= max_w) { full = true; break; }
+                        cnt = 0u;
+                        load = 0.0;
+                        add = c;
+                    }
+                    load += add;
+                    cnt++;
+                    pos++;
+                }
+            }
+            if (!full && cnt > 0u) {
+                wv++;
+                plan->chain_start[wv] = pos;
+            }
+            plan->n_chain_waves = wv;
+            plan->n_chain = plan->chain_start[wv];
+        }
         // ---- age-weighted shares: move every residency slot's weight by (mean lifetime of all light waves / its own)
         // — with equal shares the five waves of a SIMD end at 75 ... 160 Mcycles because the arbiter favours the older
         // wave; the weights that make them end together are close to 1 / lifetime after ONE measurement and settle in two or
@@ -294,14 +334,14 @@ __global__ void __launch_bounds__(256) plan_scatter(uint32_t* __restrict__ cost,
     }
 }
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, int n_cls, hipStream_t st) {
+                 int tiny_waves, int n_cu, int n_cls, int chain_on, hipStream_t st) {
     (void)hipMemsetAsync(plan, 0, offsetof(PlanBuf, age_valid), st);      // (the self-tuned age weights and the lifetimes survive)
     long long need = ((long long)np + 255) / 256, grid = (long long)n_cu * 8;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(plan_hist, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan);
     hipLaunchKernelGGL(plan_scan, dim3(1), dim3(256), 0, st, plan, np, n_waves, (uint32_t)heavy_own, (uint32_t)mean_x16, (uint32_t)bulk_x16,
-                       (uint32_t)tiny_waves, (uint32_t)n_cls);
+                       (uint32_t)tiny_waves, (uint32_t)n_cls, (uint32_t)chain_on);
     hipLaunchKernelGGL(plan_scatter, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan, order);
 }
 
@@ -367,6 +407,12 @@ void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipS
     else if (kind == KIND_BUNNY) hipLaunchKernelGGL((persistent_pool<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P, steps);
     else if (kind == KIND_MIXED) hipLaunchKernelGGL((persistent_pool<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P, steps);
     else hipLaunchKernelGGL((persistent_pool<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
+}
+void launch_chain_steps(const Params& P, int kind, int steps, int grid, hipStream_t st) {
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((chain_steps<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P, steps);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((chain_steps<KIND_BUNNY>), dim3(grid), dim3(256), 0, st, P, steps);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((chain_steps<KIND_MIXED>), dim3(grid), dim3(256), 0, st, P, steps);
+    else hipLaunchKernelGGL((chain_steps<KIND_GENERIC>), dim3(grid), dim3(256), 0, st, P, steps);
 }
 int persistent_pool_blocks_per_cu(int kind) {
     int per_cu = 0;

@@ -163,18 +163,22 @@ struct PixCtx {
 // tracked-object march below); the rest is dealt round-robin to the other waves, so every light wave gets the same cost
 // profile and, because the order is kept, starts its own heaviest pixels first in every pass.
 struct SrcWave {
-    uint32_t base, stride; // this wave's pixels in `order`: base + (k / run) * stride + k % run
+    uint32_t skip;         // entries at the head of `order` that are not the pool kernel's (the chain set)
+    uint32_t base, stride; // this wave's pixels in `order` (after `skip`): base + (k / run) * stride + k % run
     uint32_t run_inv;      // consecutive entries per round (low 6 bits; 1 = plain strided dealing) | ceil(2^20 / run) << 6
     uint32_t n_own;        // pixels owned
     uint32_t n_items;      // n_own * passes
     uint32_t s_mask;       // residency length - 1 (a power of two), ~0u when the wave keeps its pixels for the whole launch
     int lg_s;              // log2(residency length); 31 when single-pass (s >> 31 == 0)
 };
+RT_D uint32_t chain_skip(const Params& P) {      // entries of `order` that belong to the chain kernel (wave-uniform)
+    return (P.chain_on && P.order && P.plan) ? P.plan->n_chain : 0u;
+}
 RT_D uint32_t own_pixel(const Params& P, const SrcWave& Wv, uint32_t k) {
     // round r = k / run (k < 2^14: (k * ceil(2^20 / run)) >> 20, run <= 63; run = 1: r = k)
     const uint32_t run = Wv.run_inv & 63u, inv = Wv.run_inv >> 6;
     const uint32_t r = run > 1u ? (uint32_t)(((unsigned long long)k * inv) >> 20) : k;      // (64-bit: k * inv reaches 2^34)
-    const uint32_t i = Wv.base + r * Wv.stride + (k - r * run);
+    const uint32_t i = Wv.skip + Wv.base + r * Wv.stride + (k - r * run);
     return P.order ? P.order[i] : i;
 }
 
@@ -233,6 +237,9 @@ RT_D float track_decay(float lb, float s_new, float eps) { return fma_(fabs_(s_n
 // keeps lb2 valid for hundreds of steps; a ray in the WEDGE between two surfaces (a sphere resting on the ground) has
 // second ~ nearest, so lb2 fails at once — measured on the launch-critical raycasts: every lean attempt failed on its first
 // step and each step cost a full evaluation plus a wasted attempt — while lb3 holds: the two-object loop below.
+#ifndef RT_POOL_TWO
+#define RT_POOL_TWO 0      // 1: the fused pool kernel keeps both bounds too (experiment / small-frame instance)
+#endif
 struct Trk {
     float lb2, lb3;
     int k2;
@@ -562,7 +569,11 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     const uint32_t hm_cls = blockIdx.x / hm_cu, hm_b0 = hm_cls * hm_cu;
     const uint32_t hm_nb = hm_b0 + hm_cu <= gridDim.x ? hm_cu : gridDim.x - hm_b0;      // blocks in this block's residency class
     const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(hm_b0 * 4u + (uint32_t)wave * hm_nb + (blockIdx.x - hm_b0)));
-    const uint32_t np = (uint32_t)P.np;
+    // (the chain set, if there is one, is somebody else's: the ownership below deals the REST of the list)
+    Wv.skip = chain_skip(P);
+    Wv.skip = Wv.skip < (uint32_t)P.np ? Wv.skip : (uint32_t)P.np;
+    const uint32_t np_all = (uint32_t)P.np;
+    const uint32_t np = np_all - Wv.skip;
     // Heavy waves come in two sizes: the very heaviest pixels — the launch's critical path IS one of their chains — sit in
     // small waves (2 .. tiny_own pixels), where a context never waits for a lane and the lean tracked loop runs most of
     // the time; the other heavy pixels in waves of heavy_own.
@@ -571,6 +582,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     uint32_t town = (uint32_t)P.tiny_own;
     if (P.order && hown > 0u) {
         n_heavy = P.plan->n_heavy;
+        n_heavy = n_heavy > Wv.skip ? n_heavy - Wv.skip : 0u;
         n_heavy = n_heavy < np ? n_heavy : np;
         const uint32_t budget = P.plan->tiny_waves;
         if (town > 0u && budget > 0u) {
@@ -796,7 +808,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                         const uint32_t k = item - pass * Wv.n_own;
                         const uint32_t q = own_pixel(P, Wv, k);
                         int px, py;
-                        if (q < np && pixel_of(P, q, px, py)) {
+                        if (q < np_all && pixel_of(P, q, px, py)) {
                             const size_t pi = (size_t)px * P.cfg.height + py;
                             bool masked = P.cfg.adaptive_sampling && !(P.diff_pixels[pi] > P.cfg.noise_threshold);
                             if (!masked) {
@@ -920,14 +932,14 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                         int it = 1;
 #if RT_DEBUG_PHASE == 4
                         int why = 0;
-                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, &why);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, &why);
                         if (form == 1) dbg4[why]++;
                         dbg4[3 + form]++;                     // [4..7]: iterations by form
                         dbg4[7 + form] += (unsigned)it;       // [8..11]: steps by form
 #elif defined(RT_DEBUG_PHASE)
-                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds);
 #else
-                        const int form = tracked_iteration<KIND, NOBJ, SIG>(P, L, Tk, n_march, max_it, it);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it);
 #endif
                         if (form <= 2 && n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
 #ifdef RT_DEBUG_PHASE

@@ -891,3 +891,4 @@ __global__ void __launch_bounds__(256, pool_waves(KIND)) trace_paths_pool(const 
 
 #include "rt_persistent.hpp"   // the src/ persistent-ray kernels (same namespace; uses the pool above)
 #include "rt_split.hpp"        // ... and their wavefront split for launches of one bounce-step
+#include "rt_chain.hpp"        // ... and the chain kernel: the heaviest pixels of a chain-bound launch, beside the pool kernel

@@ -123,6 +123,11 @@ struct PlanBuf {
     unsigned long long total;     // sum of the costs
     uint32_t n_heavy;             // the first n_heavy entries of `order` are walked by heavy waves
     uint32_t tiny_waves;          // how many waves the small heavy waves may take (the kernel sizes them: 2, 4 or tiny_own pixels each)
+    // The CHAIN SET (rt_chain.hpp): when a launch is as long as its heaviest pixel's dependency chain, the first n_chain entries
+    // of `order` leave the pool kernel altogether and run in the chain kernel beside it, wave w on entries
+    // chain_start[w] .. chain_start[w + 1]: the heaviest pixels alone in a wave, lighter ones in twos, fours, eights.
+    uint32_t n_chain, n_chain_waves;
+    uint32_t chain_start[2049];
     // ---- everything below survives a re-plan (launch_plan clears the part above only)
     // Age-weighted shares of the light waves (rt_persistent.hpp): residency slot c of a CU (blockIdx / n_cu) takes
     // age_w[c] entries of `order` per round.  Self-tuning: every light wave adds its lifetime (cycles) to its slot's sum,
@@ -162,6 +167,7 @@ struct Params {
     uint32_t age_pack;      // ... entries of `order` per round for the waves of residency slot c: 4 bits each, slot 0 in the lowest
     int32_t tiny_own;       // src/ pool kernel: pixels per small heavy wave (the plan says how many such waves there may be)
     int32_t leave_x8;       // src/ pool kernel: cost of leaving the march loop for a shading pass, in eighths of a march iteration of the wave
+    int32_t chain_on;       // src/ pool kernel: 1 = the plan's chain set is walked by the chain kernel (rt_chain.hpp): skip it here
     int32_t src_track;      // src/ pool kernel: 1 = tracked-object march steps enabled
     int32_t heavy_prio;     // src/ pool kernel: 1 = heavy waves raise their issue priority (s_setprio)
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool

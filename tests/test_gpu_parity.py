@@ -256,6 +256,12 @@ def test_persistent_form_schedulers_agree():
                         # the wavefront split of a bounce-step (round 5: gen / march / shade kernels, rt_split.hpp) — what launches of
                         # <= src_split steps run: every step split, mixed with fused launches, on the cost-ordered list once a plan
                         # exists (tracked march for its heavy head), tiny grids, odd claim sizes, ahead-of-time and run-time instances
+                        # the chain kernel beside the pool kernel (round 5, rt_chain.hpp): on by default whenever the plan finds the launch
+                        # chain-bound (every set above that re-plans); off; with every pixel that has a cost on record heavy
+                        ({"scheduler": 1, "src_chain": 0, "plan_interval": 4}, (4, 44)),
+                        ({"scheduler": 1, "src_chain": 2, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8}, (2, 6, 40)),
+                        ({"scheduler": 1, "src_chain": 2, "plan_interval": 4, "chain_waves": 5, "grid_blocks": 3, "residency": 8}, (4, 20, 24)),
+                        ({"scheduler": 1, "src_chain": 1, "plan_interval": 8, "jit": 0, "src_track": 1}, (8, 40)),
                         ({"scheduler": 1, "src_split": 0}, (1, 1, 46)),
                         ({"scheduler": 1, "src_split": 256}, (48,)),
                         ({"scheduler": 1, "src_split": 256, "plan_interval": 4, "split_wait": 3, "grid_blocks": 2}, (5, 43)),

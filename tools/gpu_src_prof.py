@@ -52,7 +52,8 @@ if "RT_DEBUG_PHASE" in os.environ.get("RTPBR_JIT_EXTRA_FLAGS", ""):
     if 'RT_DEBUG_PHASE=3' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
         print(json.dumps({'B_pass_Mcycles': {'unpack_and_shade': d[28], 'fresh_item_loads': d[29], 'roulette_deposit_regen_writeback': d[30], 'B_pass_whole (without dispatch)': d[0], 'dispatch_swap': d[31], 'march': d[2]}}), flush=True)
     elif 'RT_DEBUG_PHASE=4' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
-        print(json.dumps({'wave0_lean_exits': {'max_it': d[16], 'raycast_ended': d[17], 'bound_failed': d[18], 'calls_with_bounded_stay': d[19]}, 'wave0_full2_lanes': {'raycast_start': d[20], 'bound_failed': d[21], 'dragged_along': d[22], 'iters_all_valid_but_different_objects': d[23]}, 'wave0_lean_steps_by_object': d[24:32]}), flush=True)
+        print(json.dumps({'wave0': {'lean1_exits(max_it,raycast_ended,bound_failed)': d[16:19], 'iterations_by_form(lean1,lean2,tracked,full)': d[20:24],
+                                    'steps_by_form': d[24:28]}}), flush=True)
     elif 'RT_DEBUG_PHASE=2' in os.environ.get('RTPBR_JIT_EXTRA_FLAGS', ''):
         print(json.dumps({'light_wave_life_hist_16Mcycle_bins': d[16:32]}), flush=True)
     elif sched == 1 and d[16]:

@@ -28,12 +28,16 @@ if rc:
     raise SystemExit("build failed: %s" % lib.rtpbr_last_error().decode())
 path = buf.value.decode()
 print(path)
-subprocess.run(["bash", os.path.join(ROOT, "tools", "jit_regs.sh"), path], check=True)
+t = path + ".o"
+subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                "--input=" + path, "--output=" + t], check=True)
+notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", t], capture_output=True, text=True, check=True).stdout
+keys = (".name:", ".vgpr_count", ".sgpr_count", "spill_count", "private_segment_fixed", "group_segment_fixed")
+rows = [l.strip() for l in notes.splitlines() if any(k in l for k in keys)]
+for i in range(0, len(rows), 7):
+    print("\t".join(rows[i:i + 7]))
 if "--asm" in sys.argv:
     out = sys.argv[sys.argv.index("--asm") + 1]
-    t = path + ".o"
-    subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                    "--input=" + path, "--output=" + t], check=True)
     with open(out, "w") as f:
         subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", t], stdout=f, check=True)
     print("disassembly ->", out)

@@ -32,6 +32,18 @@ for cfg in sorted(os.listdir(base)) if os.path.isdir(base) else []:
         entry["kernel_stats"] = ks
     f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     if f:
+        # the fused src/ kernel tunes its schedule over the first launches: list every dispatch and the settled ones (the last two)
+        per = {}
+        for r in csv.DictReader(open(f[0])):
+            n = r.get("Kernel_Name", "?")
+            if "persistent" in n:
+                per.setdefault(n, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        for n, v in per.items():
+            ms = [round(x[1], 3) for x in sorted(v)]
+            big = [m for m in ms if m > 0.5 * max(ms)]
+            settled = big[-2:]
+            lines.append(f"   dispatches {n[:50]:50s} ms in launch order {ms}; settled (last two full launches) mean {sum(settled) / len(settled):.3f}")
+            entry.setdefault("dispatch_ms", {})[n] = {"all": ms, "settled_mean": sum(settled) / len(settled)}
         seen = {}
         for r in csv.DictReader(open(f[0])):
             n = r.get("Kernel_Name", "?")
