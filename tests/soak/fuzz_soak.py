@@ -29,7 +29,14 @@ for seed in range(lo, hi):
                      {"src_plan": 0, "sparse_lanes": 64, "grid_blocks": 1, "residency": 2, "jit": 1},
                      # age-weighted shares: several blocks per CU (residency slots), self-tuned and fixed weights
                      {"plan_interval": 1, "grid_blocks": 768, "residency": 2, "jit": 1},
-                     {"plan_interval": 2, "grid_blocks": 520, "age_weights": 0x3f1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "tiny_own": 2}]
+                     {"plan_interval": 2, "grid_blocks": 520, "age_weights": 0x3f1, "heavy_mean_x16": 8, "heavy_bulk_x16": 0, "tiny_own": 2},
+                     # round 5: every bounce-step as the wavefront split (two-bound tracked march: one- and two-object lean loops) with
+                     # every pixel on the heavy head / with the one-bound march; the chain kernel beside the pool kernel, packed finely
+                     {"src_split": 256, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "jit": 1, "jit_bake": 1},
+                     {"src_split": 256, "plan_interval": 2, "sparse_lanes": 64, "split_wait": 7, "jit": 0},
+                     {"src_split": 256, "src_track": 1, "split_wait": 40, "jit": 1},
+                     {"src_split": 0, "src_chain": 2, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "chain_waves": 64, "jit": 1, "jit_bake": seed % 2},
+                     {"src_split": 0, "src_chain": 2, "plan_interval": 2, "chain_waves": 3, "grid_blocks": 2, "residency": 4, "jit": 0}]
     for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)
