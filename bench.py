@@ -254,6 +254,16 @@ def side_config(name, a, device, rank0_of=1):
            "run_time_kernels": bool(r.counter("jit_active"))}
     if wl.family == "bunny":
         out["mlp_evaluations_per_unit"] = round(r.counter("mlp_lane_evals") / max(c.samples, 1), 2)
+    if name == "c2_fast":
+        # HBM traffic of this flavour's step from the committed PMC passes (rocprofv3 cannot run inside this process): FETCH x 2 + WRITE
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_fast.json")))
+            out["hbm_fast"] = {"hbm_bytes_per_step": tj["fast"]["hbm_bytes_per_step"], "times_algorithmic": tj["fast"]["times_algorithmic"],
+                               "exact_kernels_hbm_bytes_per_step": tj["exact"]["hbm_bytes_per_step"], "exact_times_algorithmic": tj["exact"]["times_algorithmic"],
+                               "kind": "a COMMITTED constant from profiles/hbm_traffic_fast.json (separate FETCH_SIZE / WRITE_SIZE passes), not a measurement of this run",
+                               "note": "no staging in this flavour (LDS accumulators + f32 atomics); what remains is the primary records, 8 B per sample written and read"}
+        except Exception:
+            pass
     if name == "c3_valu":
         out["differs_from_c3_in"] = "mlp_mfma only (same pool kernel, same pass policy, same run-time instance)"
     r.close()
