@@ -308,6 +308,7 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, Trk& T, int k, int max_it,
     float& lb = T.lb2;
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
+    const unsigned long long mm = __ballot(marching);
     int it = 0;
     for (;;) {
         asm volatile("" : "+s"(tab));
@@ -327,10 +328,12 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, Trk& T, int k, int max_it,
             if constexpr (TWO) T.lb3 = track_decay(T.lb3, s_new, eps);
         }
         it++;
-        const bool stop = marching & (!ok | (L.state != ST_MARCH));
-        if (__any(stop) | (it >= max_it)) {
+        // (the loop's exit as lane masks in scalar registers: a lane goes on iff it stepped and still marches; written with bool
+        // selects the compiler materialised four 0/1 VGPRs and a dozen scalar instructions per step of this loop)
+        const unsigned long long live = __ballot(ok) & __ballot(L.state == ST_MARCH);
+        if ((live != mm) | (it >= max_it)) {
 #if RT_DEBUG_PHASE == 4
-            if (why) *why = __any(marching & !ok) ? 2 : (__any(stop) ? 1 : 0);      // bound failed / a raycast ended / max_it
+            if (why) *why = __any(marching & !ok) ? 2 : (live != mm ? 1 : 0);      // bound failed / a raycast ended / max_it
 #endif
             if (marching & !ok) lb = -1.0f;
             break;
@@ -360,6 +363,7 @@ template <int KIND, int NOBJ, uint32_t SIG, int A, int B>      // A >= 0: object
 RT_D int march_fast2_src_pair(const Params& P, Lane& L, Trk& T, int a, int b, int max_it) {
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
+    const unsigned long long mm = __ballot(marching);
     int it = 0;
     for (;;) {
         asm volatile("" : "+s"(tab));
@@ -387,8 +391,8 @@ RT_D int march_fast2_src_pair(const Params& P, Lane& L, Trk& T, int a, int b, in
             T.k2 = lt ? a : b;
         }
         it++;
-        const bool stop = marching & (!ok | (L.state != ST_MARCH));
-        if (__any(stop) | (it >= max_it)) {
+        const unsigned long long live = __ballot(ok) & __ballot(L.state == ST_MARCH);
+        if ((live != mm) | (it >= max_it)) {
             if (marching & !ok) T.lb3 = T.lb2 = -1.0f;
             break;
         }

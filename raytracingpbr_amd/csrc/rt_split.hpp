@@ -144,15 +144,16 @@ RT_D void src_march_impl(const Params& P) {
         const uint32_t item = g * GS + (uint32_t)lane;
         if (g != 0xffffffffu && (uint32_t)lane < GS && item < P.total_items) {
             const uint32_t q = P.order ? P.order[item] : item;
-            pf_q = q;
             int px, py;
-            pixel_of(P, q, px, py);
-            pf_pi = (uint32_t)px * (uint32_t)P.cfg.height + (uint32_t)py;
-            pf_word = P.march_out[q];
-            const float2* r = reinterpret_cast<const float2*>(P.ray_buffer + pf_pi);      // a ray record is 40 bytes, 8-byte aligned
-            pf_a = r[0];
-            pf_b = r[1];
-            pf_c = r[2];
+            if (pixel_of(P, q, px, py)) {          // (a padding pixel of an edge tile has no ray: src_gen left its word at "none")
+                pf_q = q;
+                pf_pi = (uint32_t)px * (uint32_t)P.cfg.height + (uint32_t)py;
+                pf_word = P.march_out[q];
+                const float2* r = reinterpret_cast<const float2*>(P.ray_buffer + pf_pi);      // a ray record is 40 bytes, 8-byte aligned
+                pf_a = r[0];
+                pf_b = r[1];
+                pf_c = r[2];
+            }
         }
     };
     auto group_of = [&](uint32_t claimed_v) -> uint32_t {

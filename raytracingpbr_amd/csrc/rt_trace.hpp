@@ -538,6 +538,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
 #if RT_FAST_MATH
     const AccView A = {acc_all[wave], acc_tag_all[wave]};
     if (lane < ACC_SLOTS) A.tag[lane] = 0xffffffffu;
+    lds_wave_fence();
     uint32_t n_dep = 0;
 #endif
     uint32_t (*pool)[64] = pool_all[wave];
