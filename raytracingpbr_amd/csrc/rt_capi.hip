@@ -712,6 +712,15 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                     const long long dense = (long long)P.np / 256;              // >= 64 pixels per wave
                     if (grid > dense) grid = dense;
                 }
+                // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel and needs wave slots of its own.  Frames up to about
+                // 1080p are (or may be) chain-bound — measured with the chain set beside a pool grid of four blocks per CU instead of
+                // five: 1024x576 42.8 -> 30 ms, 1280x720 46 -> 40, 1600x900 54.7 -> 50.4, 1080p 58.6 -> 57.3 — so there the pool
+                // grid makes room (whole multiples of the CU count: an uneven grid costs more than it gives).  Larger frames are
+                // throughput-bound and keep the whole device for the pool kernel (2560x1440: 97.2 against 100.3 ms).
+                const long long chain_blocks = (c->chain_waves + 3) / 4;
+                const bool chain_want = c->src_chain != 0 && c->grid_blocks == 0 && c->src_plan && (long long)P.np <= c->chain_np_max;
+                if (chain_want && grid + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu)
+                    grid = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
                 if (c->grid_blocks > 0) grid = c->grid_blocks;
                 if (grid < 1) grid = 1;
                 P.total_items = (uint32_t)P.np;
@@ -732,10 +741,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 P.age_on = c->age_on;
                 P.age_pack = 0;
                 for (int k = 0; k < 8; k++) P.age_pack |= (uint32_t)(c->age_w[k] & 15) << (4 * k);
-                // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel: only when the device has room for both — the pool
-                // grid leaves at least the chain set's waves free.  (Frames that fill the device, 1280x720 and up, are not
-                // chain-bound; there an extra kernel only takes wave slots from the pool: measured -12 % at 720p.)
-                const bool chain_fits = c->src_chain != 0 && c->grid_blocks == 0 && grid + (c->chain_waves + 3) / 4 <= max_blocks;
+                // (only when the device has room for both: more resident waves than it holds just queue the pool's last blocks
+                // behind the chain waves, measured -12 % at 720p)
+                const bool chain_fits = chain_want && grid + chain_blocks <= max_blocks;
                 const bool chain_eff = c->src_chain != 0 && (chain_fits || c->src_chain == 2);
                 if (c->src_plan) {
                     if (c->plan_np != (size_t)P.np) {
@@ -1152,6 +1160,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         c->src_chain = (int)value;
         c->order_valid = false;       // the plan carries the chain set
         c->cost_steps = 0;
+    } else if (!strcmp(key, "chain_np_max")) {
+        if (value < 0) return fail(RTPBR_EINVAL, "chain_np_max must be >= 0");
+        c->chain_np_max = value;
     } else if (!strcmp(key, "chain_waves")) {
         if (value < 1 || value > 2048) return fail(RTPBR_EINVAL, "chain_waves must be 1 .. 2048");
         c->chain_waves = (int)value;

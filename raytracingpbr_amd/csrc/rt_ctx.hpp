@@ -142,6 +142,7 @@ struct rtpbr_ctx {
     uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
     size_t march_np = 0;
     int src_chain = 1;            // src/ form, fused launches: the plan's chain set runs in the chain kernel beside the pool kernel (rt_chain.hpp)
+    long long chain_np_max = 2500000;   // ... frames of more local pixels than this are throughput-bound: no chain set
     int chain_waves = 1024;       // ... the most waves the chain set may take (<= 2048)
     hipStream_t stream2 = nullptr;      // ... on this stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
