@@ -7,10 +7,10 @@
 // the same ray_buffer (T6), each coherent in what it does:
 //   src_gen     one lane per pixel, frame order: russian_roulette + track_once (src/pathtracer.py:53-77) — roulette, deposit
 //               into image_buffer, camera-ray regeneration — and one word per pixel: "needs a raycast" + the RNG position;
-//   src_march   raycast() (src/scene.py:59-84) only.  Persistent waves are dealt groups of 64 pixels from the COST-ORDERED list of
-//               the plan kernels (heaviest first: the launch's longest raycasts start at t = 0, in the oldest waves, which the
-//               issue arbiter serves first, together, on the tracked-object march), refill finished lanes in registers, and
-//               leave the moved origin plus {hit / miss, nearest object} behind;
+//   src_march   raycast() (src/scene.py:59-84) only.  Persistent waves take groups of 32 pixels from the COST-ORDERED list of
+//               the plan kernels (heaviest first: the launch's longest raycasts start early; one claim counter per team of blocks),
+//               refill finished lanes in registers from a prefetched group, march with the two-bound tracked march where it
+//               applies, and leave the moved origin plus {hit / miss, nearest object} behind;
 //   src_shade   one lane per pixel, frame order: the rest of raytrace() (src/pathtracer.py:16-36) — surface interaction or
 //               environment lookup, stop tests — and the ray state the next launch starts from.
 // Same device functions as the fused kernels, same RNG stream positions: ray_buffer, image_buffer and the counters are bit
