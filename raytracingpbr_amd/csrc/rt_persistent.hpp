@@ -1045,6 +1045,22 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
         atomicAdd(&P.counters->dbg[15], dbg_fast_iters);
     }
 #endif
+#if RT_DEBUG_PHASE == 5
+    {   // per-wave record over diff_buffer (unused without adaptive sampling), after the chain kernel's records: who is slow?
+        const uint32_t tot = wave_sum(L.n_steps);
+        if (lane == 0) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)(4096u + blockIdx.x * 4u + (uint32_t)wave) * 8u;
+            d[0] = (unsigned long long)h | ((unsigned long long)(blockIdx.x / ((uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x)) << 32);
+            d[1] = __builtin_readcyclecounter() - t_start;
+            d[2] = heavy ? 1ull : 0ull;
+            d[3] = Wv.n_own;
+            d[4] = dbg_march_iters;
+            d[5] = dbg_passes;
+            d[6] = tot;
+            d[7] = 0x7654321ull;
+        }
+    }
+#endif
     // the light waves' lifetimes, per residency slot: what the next plan tunes the age weights with
     if (!heavy && P.age_on == 1 && P.plan && lane == 0 && Wv.n_own > 0u) {
         const uint32_t n_cu = (uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x;
