@@ -336,7 +336,8 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * "src_chain" (persistent-ray form, fused launches: 1, default = when the plan finds the launch as long as its heaviest pixel's
  * dependency chain AND the device has room beside the pool kernel's grid, the heaviest pixels — the chain set — run in the chain
  * kernel on a second stream, alone or in small groups per wave; 0 = never, 2 = whenever the plan says so), "chain_waves" (the most
- * waves the chain set may take, default 1024),
+ * waves the chain set may take, default 1024; the pool kernel's grid makes room for them), "chain_np_max" (frames of more local
+ * pixels than this are throughput-bound and get no chain set, default 2 500 000),
  * "src_split" (persistent-ray form: a launch of at most this many bounce-steps runs as a wavefront split — per step one
  * coherent kernel for roulette / deposit / camera ray, one for the raycasts on the cost-ordered pixel list, one for shading —
  * instead of the fused pool kernel; 0 = never, default 1), "split_wait" (its march kernel refills lanes when this many are

@@ -836,11 +836,14 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                             launch_chain_steps(P, c->kind, steps, cgrid, c->stream2);
                         HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
                     }
-                    if (c->jit_mod) {
-                        if (int r = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream)) return r;
-                    } else
+                    int pool_rc = RTPBR_OK;
+                    if (c->jit_mod)
+                        pool_rc = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream);
+                    else
                         launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+                    // (joined whatever happened to the pool launch: nothing that follows on the context's stream may overtake the chain kernel)
                     if (P.chain_on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+                    if (pool_rc != RTPBR_OK) return pool_rc;
                 }
             } else if (c->jit_mod) {
                 if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
