@@ -108,7 +108,10 @@ RT_D void src_march_impl(const Params& P) {
     // of a millisecond), and static shares ignore that the issue arbiter serves the OLDEST wave of a SIMD first — measured: the
     // eight waves of a SIMD need 1.4 ... 9.8 kcycles per iteration, by age, and the launch ended when the youngest were done.
     // With a counter per team the fast waves simply take more; 32 waves per counter do not contend.
-    constexpr uint32_t GS = 32;
+#ifndef RT_SPLIT_GS
+#define RT_SPLIT_GS 32      // entries per group (<= 64); measured at 1080p: 16 / 32 / 64 = 0.540 / 0.526 / 0.533 ms per launch (wall)
+#endif
+    constexpr uint32_t GS = RT_SPLIT_GS;
     const uint32_t NT = (uint32_t)P.n_teams;
     const uint32_t team = blockIdx.x % NT;
     unsigned int* const tc = P.team_counter + team * 16u;                 // one counter per 64 bytes
