@@ -333,6 +333,7 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * persistent-ray one), "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
  * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
+ * "primary_lean" (1, default: the coherent primary-ray kernel marches on in a one-object loop while its whole wave needs one object),
  * "src_chain" (persistent-ray form, fused launches: 1, default = when the plan finds the launch as long as its heaviest pixel's
  * dependency chain AND the device has room beside the pool kernel's grid, the heaviest pixels — the chain set — run in the chain
  * kernel on a second stream, alone or in small groups per wave; 0 = never, 2 = whenever the plan says so), "chain_waves" (the most

@@ -103,6 +103,7 @@ struct rtpbr_ctx {
     size_t stage_cap = 0;  // bytes
     float2* primary = nullptr;
     size_t primary_cap = 0;
+    int primary_lean = 1;    // one-object lean loop in the primary kernel
     int primary_split = 1;
     int specialize = 1;      // use the RT_BOX_SIGNATURES instance the scene fits
     int lazy_sqrt = 1;       // all-box scenes: nearest box on squared distances (nearest_boxes_lazy)

@@ -669,7 +669,7 @@ RT_D float sdf_object(const Params& P, int kw, vec3 p) {
 // fewer than NOBJ objects (runtime count, compile-time unrolling).
 template <int KIND, int NOBJ, uint32_t SIG = 0>
 RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub, float (&lb)[NOBJ > 0 ? NOBJ : 1],
-                         int& idx, float& best, uint32_t* dbg_evaluated = nullptr) {
+                         int& idx, float& best, uint32_t* dbg_evaluated = nullptr, uint32_t* ev_mask = nullptr) {
     static_assert(NOBJ > 0, "culling needs a compile-time object count");
     ObjTab tab = obj_table();
     asm volatile("" : "+s"(tab));
@@ -688,9 +688,10 @@ RT_D void nearest_culled(const Params& P, vec3 p, float t, bool active, float ub
         // !(lb > bound); __all / __ballot cost two more VALU instructions per object here)
         if ((__builtin_amdgcn_fcmpf(lb[i], bound, 13) & act_mask) == 0ull) return;
         const ObjM o = load_obj<SIG, i>(tab);
-#if defined(RT_DEBUG_PHASE) || defined(RT_DEBUG_CULL)
+#if defined(RT_DEBUG_PHASE) || defined(RT_DEBUG_CULL) || defined(RT_DEBUG_PRIMARY)
         if (dbg_evaluated) (*dbg_evaluated)++;
 #endif
+        if (ev_mask) *ev_mask |= 1u << i;        // (wave-uniform: a scalar or)
         float d = fabs_(signed_distance<KIND>(P, o, p, RT_SIG_CLS(i), jit_type(i)));
         lb[i] = d - eps;
         bool take = first || d < best;                            // nearest_init = 0: the first visited object initialises

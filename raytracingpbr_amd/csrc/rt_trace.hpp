@@ -310,12 +310,65 @@ __global__ void __launch_bounds__(256) trace_paths(const Params P) {
 // {t_eval, nearest index, hit/miss} — is written per item and the pool kernel resumes the path
 // from there (it regenerates the camera ray from the same RNG stream: cheaper than moving 24 more
 // bytes per sample).  Same arithmetic as the pool kernel's march, bit-identical results.
+// The ONE-OBJECT loop of the coherent primary march (round 5).  Measured (tools/gpu_dbg_primary.py): after wave-level culling
+// 43 % of the wave-steps of the Cornell headline (38 % of the Tokyo frame's) evaluate exactly ONE object — the 64 camera rays of
+// a pixel fly towards the same wall — and still pay the eight skip tests and eight bound updates of the culled step (~170
+// instructions against ~65 for the object itself plus the raycast bookkeeping).  When a culled step has evaluated only object K
+// for the whole wave, the march continues HERE: one bound for all other objects (lbo = the smallest of their lower bounds,
+// decayed by the path marched), one wave vote per step — the same criterion nearest_culled applies per object, on the minimum —
+// object K evaluated exactly as nearest_culled evaluates it, so (index, distance) and everything downstream are bit for bit
+// the same.  The loop ends when some lane can no longer exclude the others (nothing has been stepped then) or all rays are done;
+// the per-object bounds are brought up to date on the way out (the others by the path marched inside, rounded UP).
+template <int KIND, int NOBJ, uint32_t SIG, int K>
+RT_D void primary_lean_obj(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ > 0 ? NOBJ : 1], uint32_t& n_iter) {
+    ObjTab tab = obj_table();
+    float lbo = 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NOBJ; j++)
+        if (j != K && (SIG != 0 || j < P.n_obj)) lbo = fmin_(lbo, lb[j]);
+    float acc = 0.0f, lbk = lb[K];
+    for (;;) {
+        asm volatile("" : "+s"(tab));
+        const bool active = L.state == ST_MARCH;
+        const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
+        if (act_mask == 0ull) break;
+        const float eps = 1.9073486328125e-06f * (fabs_(L.t) + P.cull_extent);
+        const float bound = ub + eps;
+        // some lane cannot exclude every other object: back to the culled step (13 = "unordered or <=", i.e. !(lbo > bound))
+        if ((__builtin_amdgcn_fcmpf(lbo, bound, 13) & act_mask) != 0ull) break;
+        const vec3 pos = fma3(L.t, L.d, L.o);
+        const float t_before = L.t;
+        const ObjM o = load_obj<SIG, K>(tab);
+        const float d = fabs_(signed_distance<KIND>(P, o, pos, RT_SIG_CLS(K), jit_type(K)));
+        // what nearest_culled returns when K is the only object it visits: K initialises the search (nearest_init = 0) or has
+        // to beat MAX_DIS (nearest_init = 1)
+        const bool take = !P.cfg.nearest_init | (d < P.cfg.max_dis);
+        if (active) {
+            L.t_eval = L.t;
+            march_update(P, L, take ? K : 0, take ? d : P.cfg.max_dis);
+        }
+        const float moved = fabs_(L.t - t_before) * 1.000001f;
+        ub = (take ? d : P.cfg.max_dis) + moved;
+        lbo -= moved;
+        acc += moved;
+        lbk = (d - eps) - moved;
+        n_iter++;
+    }
+    // bounds of the culled step, as it would have left them (the others: minus the whole path, rounded up — a lower bound stays one)
+    const float dec = acc * 1.000002f;
+#pragma unroll
+    for (int j = 0; j < NOBJ; j++) lb[j] = j == K ? lbk : lb[j] - dec;
+}
+
 template <int KIND, int NOBJ, uint32_t SIG = 0, bool CULL = true>
 RT_D void primary_rays_impl(const Params& P) {
     const int lane = threadIdx.x & 63;
     const uint32_t n_groups = (P.total_items + 63u) / 64u;
     const uint32_t n_waves = gridDim.x * 4u;
     uint32_t n_steps = 0, n_raycasts = 0;
+#ifdef RT_DEBUG_PRIMARY
+    uint32_t dbg_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // persistent waves (a few thousand resident blocks; one block per 256 items would be
     // dispatch-bound: 2 M blocks of ~10 us each) that CLAIM runs of up to 16 consecutive groups of 64
     // items from a counter: a static stride leaves the slowest wave's tail exposed (average wave
@@ -365,7 +418,14 @@ RT_D void primary_rays_impl(const Params& P) {
                 int idx;
                 float dist;
                 // all lanes run the (wave-uniform) object loop; finished lanes just do not commit
-                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist);
+                uint32_t ev_mask = 0;
+#ifdef RT_DEBUG_PRIMARY      // measurement build: how many objects a wave-step of the coherent primary march evaluates (histogram in dbg[0..8])
+                uint32_t dbg_ev = 0;
+                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist, &dbg_ev, &ev_mask);
+                dbg_hist[dbg_ev < 8u ? dbg_ev : 8u]++;
+#else
+                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist, nullptr, &ev_mask);
+#endif
                 if (active) {
                     L.t_eval = L.t;
                     march_update(P, L, idx, dist);
@@ -375,6 +435,18 @@ RT_D void primary_rays_impl(const Params& P) {
                 ub = dist + moved;
 #pragma unroll
                 for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
+                // the wave needed exactly one object: go on in its lean loop (primary_lean_obj above)
+                if (P.primary_lean && (ev_mask & (ev_mask - 1u)) == 0u && ev_mask != 0u) {
+                    const int k = (int)__builtin_ctz(ev_mask);
+                    uint32_t lean_iters = 0;
+                    static_for<(NOBJ > 0 ? NOBJ : 1), 1>([&](auto Ic) {
+                        constexpr int i = decltype(Ic)::value;
+                        if (k == i) primary_lean_obj<KIND, NOBJ, SIG, i>(P, L, ub, lb, lean_iters);
+                    });
+#ifdef RT_DEBUG_PRIMARY
+                    dbg_hist[0] += lean_iters;      // (bin 0 is otherwise empty: wave-steps taken inside the lean loop)
+#endif
+                }
             }
         } else {
             while (__any(L.state == ST_MARCH)) {
@@ -388,6 +460,10 @@ RT_D void primary_rays_impl(const Params& P) {
         n_steps += L.n_steps;
         n_raycasts += L.n_raycasts;
     }
+#ifdef RT_DEBUG_PRIMARY
+    if (lane == 0)
+        for (int i = 0; i < 9; i++) atomicAdd(&P.counters->dbg[i], (unsigned long long)dbg_hist[i]);
+#endif
     flush_counters(P, n_steps, n_raycasts, 0, 0, 0, 0);
 }
 
