@@ -333,6 +333,8 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * persistent-ray one), "refill_lanes", "ready_low" (scheduler 1), "waves_per_cu",
  * "residency" (persistent-ray form, pool scheduler: bounce-steps a pixel stays resident in a wave that owns more pixels
  * than the 128 it can hold; a power of two, default 32), "grid_blocks" (same kernel: workgroups to launch, 0 = automatic),
+ * "drain_lanes" (complete-path pool kernel: once the work has run out and nothing is parked, a wave with at most this many marching
+ * lanes finishes their raycasts in the culled wave march of the primary kernel; default 16, 0 = never),
  * "primary_lean" (1, default: the coherent primary-ray kernel marches on in a one-object loop while its whole wave needs one object),
  * "src_chain" (persistent-ray form, fused launches: 1, default = when the plan finds the launch as long as its heaviest pixel's
  * dependency chain AND the device has room beside the pool kernel's grid, the heaviest pixels — the chain set — run in the chain

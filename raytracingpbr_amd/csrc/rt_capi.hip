@@ -881,6 +881,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
             P.primary = c->primary;
             P.primary_split = split ? 1 : 0;
             P.primary_lean = c->primary_lean;
+            P.drain_lanes = c->drain_lanes;
             P.stage = c->stage;
             P.K = K;
             P.sample_base = c->sample_base;
@@ -1226,6 +1227,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "primary_split")) {
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "primary_split must be 0 (never), 1 (large launches) or 2 (always)");
         c->primary_split = (int)value;
+    } else if (!strcmp(key, "drain_lanes")) {
+        if (value < 0 || value > 64) return fail(RTPBR_EINVAL, "drain_lanes must be 0..64");
+        c->drain_lanes = (int)value;
     } else if (!strcmp(key, "primary_lean")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "primary_lean must be 0 or 1");
         c->primary_lean = (int)value;

@@ -103,6 +103,7 @@ struct rtpbr_ctx {
     size_t stage_cap = 0;  // bytes
     float2* primary = nullptr;
     size_t primary_cap = 0;
+    int drain_lanes = 16;    // complete-path pool kernel: culled wave march for the drain (<= this many lanes marching, work exhausted)
     int primary_lean = 1;    // one-object lean loop in the primary kernel
     int primary_split = 1;
     int specialize = 1;      // use the RT_BOX_SIGNATURES instance the scene fits

@@ -360,6 +360,51 @@ RT_D void primary_lean_obj(const Params& P, Lane& L, float& ub, float (&lb)[NOBJ
     for (int j = 0; j < NOBJ; j++) lb[j] = j == K ? lbk : lb[j] - dec;
 }
 
+// The wave's marching lanes marched TO THE END OF THEIR RAYCASTS with wave-level culling: every lane keeps a lower bound per
+// object (last exact distance minus the path marched since) and an upper bound of its minimum; an object no marching lane can
+// need is skipped (nearest_culled, exact), and while the whole wave needs one object only the march goes on in that object's
+// lean loop (primary_lean_obj).  Used by the coherent primary kernel (64 camera rays of one pixel) and by the pool kernel's
+// DRAIN (the work has run out, a handful of lanes still march: with so few rays nearly every object can be excluded).
+// dbg_hist (measurement build): objects evaluated per wave-step, bin 0 = steps inside lean loops.
+template <int KIND, int NOBJ, uint32_t SIG>
+RT_D void culled_march_wave(const Params& P, Lane& L, uint32_t* dbg_hist) {
+    float lb[NOBJ > 0 ? NOBJ : 1];
+#pragma unroll
+    for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] = -1.0f;   // nothing known yet: everything is evaluated
+    float ub = 3.0e38f;
+    while (__any(L.state == ST_MARCH)) {
+        const bool active = L.state == ST_MARCH;
+        vec3 pos = fma3(L.t, L.d, L.o);
+        const float t_before = L.t;
+        int idx;
+        float dist;
+        // all lanes run the (wave-uniform) object loop; finished lanes just do not commit
+        uint32_t ev_mask = 0;
+        uint32_t dbg_ev = 0;
+        nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist, dbg_hist ? &dbg_ev : nullptr, &ev_mask);
+        if (dbg_hist) dbg_hist[dbg_ev < 8u ? dbg_ev : 8u]++;
+        if (active) {
+            L.t_eval = L.t;
+            march_update(P, L, idx, dist);
+        }
+        // the next evaluation point is |dt| * |d| away; |d| <= 1 + 2^-20
+        const float moved = fabs_(L.t - t_before) * 1.000001f;
+        ub = dist + moved;
+#pragma unroll
+        for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
+        // the wave needed exactly one object: go on in its lean loop (primary_lean_obj above)
+        if (P.primary_lean && (ev_mask & (ev_mask - 1u)) == 0u && ev_mask != 0u) {
+            const int k = (int)__builtin_ctz(ev_mask);
+            uint32_t lean_iters = 0;
+            static_for<(NOBJ > 0 ? NOBJ : 1), 1>([&](auto Ic) {
+                constexpr int i = decltype(Ic)::value;
+                if (k == i) primary_lean_obj<KIND, NOBJ, SIG, i>(P, L, ub, lb, lean_iters);
+            });
+            if (dbg_hist) dbg_hist[0] += lean_iters;      // (bin 0 is otherwise empty: wave-steps taken inside the lean loop)
+        }
+    }
+}
+
 template <int KIND, int NOBJ, uint32_t SIG = 0, bool CULL = true>
 RT_D void primary_rays_impl(const Params& P) {
     const int lane = threadIdx.x & 63;
@@ -407,47 +452,11 @@ RT_D void primary_rays_impl(const Params& P) {
             }
         }
         if constexpr (CULL && NOBJ > 0 && KIND != KIND_BUNNY && KIND != KIND_MIXED) {
-            float lb[NOBJ > 0 ? NOBJ : 1];
-#pragma unroll
-            for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] = -1.0f;   // nothing known yet: everything is evaluated
-            float ub = 3.0e38f;
-            while (__any(L.state == ST_MARCH)) {
-                const bool active = L.state == ST_MARCH;
-                vec3 pos = fma3(L.t, L.d, L.o);
-                const float t_before = L.t;
-                int idx;
-                float dist;
-                // all lanes run the (wave-uniform) object loop; finished lanes just do not commit
-                uint32_t ev_mask = 0;
-#ifdef RT_DEBUG_PRIMARY      // measurement build: how many objects a wave-step of the coherent primary march evaluates (histogram in dbg[0..8])
-                uint32_t dbg_ev = 0;
-                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist, &dbg_ev, &ev_mask);
-                dbg_hist[dbg_ev < 8u ? dbg_ev : 8u]++;
-#else
-                nearest_culled<KIND, NOBJ, SIG>(P, pos, L.t, active, ub, lb, idx, dist, nullptr, &ev_mask);
-#endif
-                if (active) {
-                    L.t_eval = L.t;
-                    march_update(P, L, idx, dist);
-                }
-                // the next evaluation point is |dt| * |d| away; |d| <= 1 + 2^-20
-                const float moved = fabs_(L.t - t_before) * 1.000001f;
-                ub = dist + moved;
-#pragma unroll
-                for (int i = 0; i < (NOBJ > 0 ? NOBJ : 1); i++) lb[i] -= moved;
-                // the wave needed exactly one object: go on in its lean loop (primary_lean_obj above)
-                if (P.primary_lean && (ev_mask & (ev_mask - 1u)) == 0u && ev_mask != 0u) {
-                    const int k = (int)__builtin_ctz(ev_mask);
-                    uint32_t lean_iters = 0;
-                    static_for<(NOBJ > 0 ? NOBJ : 1), 1>([&](auto Ic) {
-                        constexpr int i = decltype(Ic)::value;
-                        if (k == i) primary_lean_obj<KIND, NOBJ, SIG, i>(P, L, ub, lb, lean_iters);
-                    });
 #ifdef RT_DEBUG_PRIMARY
-                    dbg_hist[0] += lean_iters;      // (bin 0 is otherwise empty: wave-steps taken inside the lean loop)
+            culled_march_wave<KIND, NOBJ, SIG>(P, L, dbg_hist);
+#else
+            culled_march_wave<KIND, NOBJ, SIG>(P, L, nullptr);
 #endif
-                }
-            }
         } else {
             while (__any(L.state == ST_MARCH)) {
                 if (L.state == ST_MARCH) march_step<KIND, NOBJ, SIG>(P, L);
@@ -835,6 +844,18 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                 continue;
             }
             const int n_ready = __popcll(m_ready);
+            // DRAIN: the work has run out, nothing is parked READY and a handful of lanes still march — what is left of the launch
+            // is these rays' dependent steps.  They go on to the end of their raycasts in the culled wave march of the primary
+            // kernel (exact: same (index, distance) per step): with so few rays nearly every object can be excluded, and a lone
+            // ray runs its object's lean loop.
+            if constexpr (NOBJ > 0 && (KIND == KIND_BOXES || KIND == KIND_GENERIC)) {
+                if (wr.drained && n_ready == 0 && n_march <= P.drain_lanes && P.cull_ok) {
+                    const uint32_t s0 = L.n_steps;
+                    culled_march_wave<KIND, NOBJ, SIG>(P, L, nullptr);
+                    w_steps += wave_sum(L.n_steps - s0);
+                    continue;
+                }
+            }
             int n_done;
             // bunny: position evaluated (local point b_lp), MLP still to run.  Lanes still waiting when the march phase
             // is left re-derive their point on re-entry (the cheap half of the step; nothing has been counted yet)

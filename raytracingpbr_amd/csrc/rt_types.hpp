@@ -178,6 +178,7 @@ struct Params {
     float* stage;           // 3 floats per work item (StageRec)
     float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
+    int32_t drain_lanes;    // pool kernel, work exhausted: at most this many marching lanes go on in the culled wave march (0 = never)
     int32_t primary_lean;   // ... whose march goes on in a one-object loop while the whole wave needs one object only (primary_lean_obj)
     uint32_t box_sig;       // host side: which RT_BOX_SIGNATURES instance to launch (0 = general)
     int32_t cull_ok;        // host side: every shape is 1-Lipschitz and n_obj <= 8: primary_rays may cull (nearest_culled)

@@ -152,7 +152,9 @@ def test_schedule_independence():
                  {"staging_bytes": 1 << 20}, {"waves_per_cu": 1},
                  {"primary_split": 0}, {"primary_split": 2}, {"specialize": 0}, {"primary_split": 0, "specialize": 0},
                  {"primary_split": 2, "specialize": 0}, {"primary_split": 2, "staging_bytes": 1 << 20, "shade_lanes": 3},
-                 {"lazy_sqrt": 0}, {"lazy_sqrt": 0, "specialize": 0, "scheduler": 0}):
+                 {"lazy_sqrt": 0}, {"lazy_sqrt": 0, "specialize": 0, "scheduler": 0},
+                 # the drain's culled wave march (round 5): never / for every wave once the work has run out; with and without its lean loop
+                 {"drain_lanes": 0}, {"drain_lanes": 64}, {"drain_lanes": 64, "jit": 2, "chunk": 64}, {"drain_lanes": 3, "primary_lean": 0, "jit": 2, "jit_bake": 1}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
