@@ -92,6 +92,8 @@ bool source_hash(const std::string& dir, uint64_t* h) {
         if (!read_file(dir + "/" + f, buf)) return false;
         for (char c : buf) x = (x ^ (unsigned char)c) * 1099511628211ull;
     }
+    // ... and the command line compile() builds is part of the product too: bump when its flags change
+    for (const char* c = "flags-r5b"; *c; c++) x = (x ^ (unsigned char)*c) * 1099511628211ull;
     *h = x;
     return true;
 }
@@ -317,6 +319,10 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         argv[5] = "-ffp-contract=fast";
         // (-munsafe-fp-atomics: the f32 adds into image_buffer as hardware atomics, not compare-and-swap loops)
         argv.insert(argv.begin() + 10, {"-DRT_FAST_MATH=1", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics"});
+        // all-box scenes (kind 1 = KIND_BOXES): the root of a box distance is of the distance's own magnitude (|sqrt(s2) / 2 - rho|, rho
+        // small), so the bare v_sqrt_f32 (<= 1 ulp) does without the correction step the sphere scenes need (rt_math.hpp sqrt_fast_):
+        // Cornell headline 4974 -> 5366 Msamples/s, whole-frame L2 against the exact kernels 6.69e-4 -> 6.71e-4
+        if (key.kind == 1) argv.insert(argv.begin() + 10, "-DRT_FAST_HW_SQRT=1");
     }
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     argv.insert(argv.begin() + 10, extra.begin(), extra.end());

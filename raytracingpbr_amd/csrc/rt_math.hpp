@@ -68,7 +68,9 @@ RT_HD float dot(vec3 a, vec3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x
 // of 11 — a bare v_sqrt_f32 is NOT enough here: |sqrt(s2) - r| cancels against the 100-unit ground sphere of the src /
 // Tokyo scenes, 1 ulp of 100 is 7.6e-6, and hit thresholds are ~1e-4 t (measured: 0.8 % of the samples changed colour)
 RT_HD float sqrt_fast_(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RT_FAST_HW_SQRT)
+    return __builtin_amdgcn_sqrtf(x);      // all-box scenes: no large cancellation behind the root (see rt_jit.hip)
+#elif defined(__HIP_DEVICE_COMPILE__)
     const float y = __builtin_amdgcn_sqrtf(x);
     const float h = 0.5f * __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 1.0e-36f));
     return __builtin_fmaf(__builtin_fmaf(-y, y, x), h, y);
