@@ -258,7 +258,8 @@ RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
 RT_D float sd_box(vec3 l, float sx, float sy, float sz, float rho) {
     float qx = fabs_(l.x) - sx, qy = fabs_(l.y) - sy, qz = fabs_(l.z) - sz;
     vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
-    return (length(m) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+    // (the root is the distance to the box's core: never large where it matters)
+    return (sqrt_shape_(dot(m, m), false) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
 }
 
 template <int KIND>
@@ -267,17 +268,18 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
     if (KIND == KIND_BUNNY) return sd_bunny(P.bunny, l);
     switch (type) {
         case RTPBR_SHAPE_SPHERE:
-            return length(l) - sx;
+            return sqrt_shape_(dot(l, l), sx > RT_BIG_EXTENT) - sx;
         case RTPBR_SHAPE_BOX:
             return sd_box(l, sx, sy, sz, P.cfg.box_round);
         case RTPBR_SHAPE_CYLINDER: {
-            float r = sqrt_(fma_(l.z, l.z, l.x * l.x));
+            const bool big = sx > RT_BIG_EXTENT || sy > RT_BIG_EXTENT;
+            float r = sqrt_shape_(fma_(l.z, l.z, l.x * l.x), big);
             float dx = fabs_(r) - sx, dy = fabs_(l.y) - sy;
             float mx = fmax_(dx, 0.0f), my = fmax_(dy, 0.0f);
-            return fmin_(fmax_(dx, dy), 0.0f) + sqrt_(fma_(my, my, mx * mx));
+            return fmin_(fmax_(dx, dy), 0.0f) + sqrt_shape_(fma_(my, my, mx * mx), big);
         }
         case RTPBR_SHAPE_CONE: {
-            float q = sqrt_(fma_(l.z, l.z, l.x * l.x));
+            float q = sqrt_shape_(fma_(l.z, l.z, l.x * l.x), sy > RT_BIG_EXTENT);
             return fmax_(fma_(sz, l.y, sx * q), -sy - l.y);
         }
         case RTPBR_SHAPE_PLANE:
@@ -927,7 +929,7 @@ RT_D vec3 hemispheric_sampling(vec3 n, uint32_t key, uint32_t& cnt) {
     float ang = b * 2.0f * PI;
     float sn, cs;
     sincos_(ang, &sn, &cs);
-    float sq = sqrt_(1.0f - z * z);
+    float sq = sqrt_shape_(1.0f - z * z, false);      // (a direction component: no cancellation behind the root)
     vec3 u = mk(sq * sn, sq * cs, z);
     return normalize(n + u);
 }
@@ -986,7 +988,7 @@ RT_D void surface_interaction(const Params& P, const ObjFull& o, vec3 pos, vec3&
     } else {
         float c2 = rng_next(key, cnt);
         if (c2 < o.transmission) {
-            float f = sqrt_(k) + eta * NoI;
+            float f = sqrt_shape_(k, false) + eta * NoI;
             D = mk(eta * I.x - f * N.x, eta * I.y - f * N.y, eta * I.z - f * N.z);
         } else {
             D = hemi;
@@ -1042,7 +1044,7 @@ RT_D void gen_ray(const Params& P, int px, int py, uint32_t key, uint32_t& cnt, 
         float ang = b * 2.0f * PI;
         float sn, cs;
         sincos_(ang, &sn, &cs);
-        float r = sqrt_(a);
+        float r = sqrt_shape_(a, false);
         float rx = f.lens_radius * (r * sn), ry = f.lens_radius * (r * cs);
         vec3 off = fma3(ry, mk(f.y[0], f.y[1], f.y[2]), mk(f.x[0], f.x[1], f.x[2]) * rx);
         ro = lf + off;

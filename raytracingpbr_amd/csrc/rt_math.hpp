@@ -114,6 +114,18 @@ RT_HD float sqrt_quarter_(float x) {
 #endif
 }
 RT_HD float sqrt_ieee_(float x) { return __builtin_sqrtf(x); }
+// The root inside a shape's distance.  Exact flavour: sqrt_.  Tolerance flavour: the correction step of sqrt_fast_ only where
+// the root cancels against something LARGE (`big`: the shape's radius / half-height above RT_BIG_EXTENT — the 100-unit ground
+// spheres of the src/ and Tokyo scenes, whose 1 ulp is 7.6e-6 against hit thresholds of ~1e-4 t); for a shape of a few units
+// a bare v_sqrt_f32 is off by less than the rounding of the position that went in.
+#define RT_BIG_EXTENT 16.0f
+RT_HD float sqrt_shape_(float x, bool big) {
+#if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT) && defined(__HIP_DEVICE_COMPILE__)
+    if (!big) return __builtin_amdgcn_sqrtf(x);
+#endif
+    (void)big;
+    return sqrt_(x);
+}
 RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
 RT_HD vec3 normalize(vec3 a) {
 #if RT_FAST_MATH
