@@ -268,7 +268,7 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
     if (KIND == KIND_BUNNY) return sd_bunny(P.bunny, l);
     switch (type) {
         case RTPBR_SHAPE_SPHERE:
-            return sqrt_shape_(dot(l, l), sx > RT_BIG_EXTENT) - sx;
+            return (sx > RT_BIG_EXTENT ? sqrt_big_sphere_(dot(l, l), sx) : sqrt_shape_(dot(l, l), false)) - sx;
         case RTPBR_SHAPE_BOX:
             return sd_box(l, sx, sy, sz, P.cfg.box_round);
         case RTPBR_SHAPE_CYLINDER: {
