@@ -292,6 +292,21 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
     }
 }
 
+// a x + b y of a single-axis rotation.  Tolerance flavour, baked table: the run-time compiler snaps matrix entries within 2^-20 of
+// 0 / +-1 (rt_jit.hip: cosf of a right angle is -4.4e-8, not 0) and a rotation by a right angle becomes what it is, a signed
+// permutation — no arithmetic at all; dropping a 4.4e-8 x term moves a position by less than half an ulp of the room.
+RT_D float rot2(float a, float x, float b, float y) {
+#if RT_FAST_MATH && defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_constant_p(a) && __builtin_constant_p(b)) {
+        if (a == 0.0f && b == 1.0f) return y;
+        if (a == 0.0f && b == -1.0f) return -y;
+        if (b == 0.0f && a == 1.0f) return x;
+        if (b == 0.0f && a == -1.0f) return -x;
+    }
+#endif
+    return fma_(b, y, a * x);
+}
+
 // F9 world -> local (src/sdf.py:64-68) + the bunny's per-frame animation (bunny_sdf_glass.py:213-217)
 template <int KIND, typename OBJ>
 RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL) {
@@ -303,9 +318,9 @@ RT_D vec3 to_local(const Params& P, const OBJ& o, vec3 p, int cls = ROT_GENERAL)
         // rtpbr_set_scene.  Dropping the x*0 and x*1 terms of the fma chain is exact for finite
         // positions up to the sign of a zero result, and the box SDF only sees |l|.
         if (cls == ROT_IDENT) return d;
-        if (cls == ROT_X) return mk(d.x, fma_(o.m[5], d.z, o.m[4] * d.y), fma_(o.m[8], d.z, o.m[7] * d.y));
-        if (cls == ROT_Y) return mk(fma_(o.m[2], d.z, o.m[0] * d.x), d.y, fma_(o.m[8], d.z, o.m[6] * d.x));
-        if (cls == ROT_Z) return mk(fma_(o.m[1], d.y, o.m[0] * d.x), fma_(o.m[4], d.y, o.m[3] * d.x), d.z);
+        if (cls == ROT_X) return mk(d.x, rot2(o.m[4], d.y, o.m[5], d.z), rot2(o.m[7], d.y, o.m[8], d.z));
+        if (cls == ROT_Y) return mk(rot2(o.m[0], d.x, o.m[2], d.z), d.y, rot2(o.m[6], d.x, o.m[8], d.z));
+        if (cls == ROT_Z) return mk(rot2(o.m[0], d.x, o.m[1], d.y), rot2(o.m[3], d.x, o.m[4], d.y), d.z);
     }
     vec3 l = mulv(o.m, d);
     if (KIND == KIND_BUNNY || (KIND == KIND_MIXED && o.type == RTPBR_SHAPE_BUNNY)) {

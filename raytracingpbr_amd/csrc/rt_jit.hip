@@ -93,7 +93,7 @@ bool source_hash(const std::string& dir, uint64_t* h) {
         for (char c : buf) x = (x ^ (unsigned char)c) * 1099511628211ull;
     }
     // ... and the command line compile() builds is part of the product too: bump when its flags change
-    for (const char* c = "flags-r5b"; *c; c++) x = (x ^ (unsigned char)*c) * 1099511628211ull;
+    for (const char* c = "flags-r5c"; *c; c++) x = (x ^ (unsigned char)*c) * 1099511628211ull;
     *h = x;
     return true;
 }
@@ -274,7 +274,19 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         fprintf(f, "static constexpr uint32_t RT_JIT_TABLE_BITS[%d][16] = {\n", key.n_obj);
         for (int i = 0; i < key.n_obj; i++) {
             fprintf(f, "    {");
-            for (int k = 0; k < 16; k++) fprintf(f, "0x%08xu%s", key.table[i * 16 + k], k < 15 ? ", " : "");
+            for (int k = 0; k < 16; k++) {
+                uint32_t w = key.table[i * 16 + k];
+                if (key.fast && k >= 3 && k < 12) {
+                    // tolerance flavour: a matrix entry within 2^-20 of 0 / +-1 IS 0 / +-1 (to_local's rot2 then drops the arithmetic)
+                    float v;
+                    memcpy(&v, &w, 4);
+                    const float a = v < 0 ? -v : v;
+                    if (a < 9.5367431640625e-07f) v = 0.0f;
+                    else if (a > 1.0f - 9.5367431640625e-07f && a < 1.0f + 9.5367431640625e-07f) v = v < 0 ? -1.0f : 1.0f;
+                    memcpy(&w, &v, 4);
+                }
+                fprintf(f, "0x%08xu%s", w, k < 15 ? ", " : "");
+            }
             fprintf(f, "},\n");
         }
         fprintf(f, "};\n");
