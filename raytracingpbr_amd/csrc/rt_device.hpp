@@ -257,9 +257,21 @@ RT_D float sd_bunny(const float* __restrict__ wg, vec3 p) {
 // src/sdf.py:21-51 (l = local position, s = transform.scale); box rounding rho per variant
 RT_D float sd_box(vec3 l, float sx, float sy, float sz, float rho) {
     float qx = fabs_(l.x) - sx, qy = fabs_(l.y) - sy, qz = fabs_(l.z) - sz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // |max(q, 0)| as sqrt(|q + |q||^2 / 4): q + |q| = 2 max(q, 0) exactly, the scaling by 4 commutes with every rounding of the
+    // dot product and sqrt_quarter_ takes it back inside the root's own scaling — bit for bit the reference's length(max(q, 0)),
+    // with three full-rate adds (abs source modifier) in place of three half-rate v_max_f32 (as in nearest_boxes_lazy)
+    vec3 u = mk(qx + fabs_(qx), qy + fabs_(qy), qz + fabs_(qz));
+#if RT_FAST_MATH      // (the root is the distance to the box's core: never large where it matters — the bare instruction)
+    const float len = 0.5f * sqrt_shape_(dot(u, u), false);
+#else
+    const float len = sqrt_quarter_(dot(u, u));
+#endif
+    return (len + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+#else
     vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
-    // (the root is the distance to the box's core: never large where it matters)
-    return (sqrt_shape_(dot(m, m), false) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+    return (sqrt_(dot(m, m)) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+#endif
 }
 
 template <int KIND>
