@@ -721,6 +721,18 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 const bool chain_want = c->src_chain != 0 && c->grid_blocks == 0 && c->src_plan && (long long)P.np <= c->chain_np_max;
                 if (chain_want && grid + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu)
                     grid = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
+                // Beside the chain kernel a pool wave should own ~190 pixels, in whole blocks per CU, never fewer than two waves per
+                // SIMD.  A small frame has a fixed number of contexts per SIMD (324 at 768x432): three waves of 108 march with 34 of
+                // their 64 lanes, two waves of 162 with 54-57 (per-wave records, tools/gpu_pool_simd.py) — and a wave issues one
+                // instruction per ~6.5 cycles however many lanes it carries, so lane-steps per SIMD cycle are 2 / 6.5 x 57 against
+                // 3 / 7.8 x 36.  Measured, ms per 256 steps: 1024x576 four -> three blocks per CU 30.8 -> 27.3, 960x540 29.5 -> 24.2,
+                // 768x432 three -> two 22.7 -> 22.3; one block per CU 37 (one wave cannot hide its own latencies); without the
+                // chain kernel the heaviest pixels need the larger grid: 26 against 36 at 768x432.
+                if (chain_want) {
+                    long long want = ((long long)P.np / 760 + c->n_cu / 2) / c->n_cu * c->n_cu;
+                    if (want < 2LL * c->n_cu) want = 2LL * c->n_cu;
+                    if (grid > want) grid = want;
+                }
                 if (c->grid_blocks > 0) grid = c->grid_blocks;
                 if (grid < 1) grid = 1;
                 P.total_items = (uint32_t)P.np;

@@ -1052,7 +1052,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
             unsigned long long* d = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)(4096u + blockIdx.x * 4u + (uint32_t)wave) * 8u;
             d[0] = (unsigned long long)h | ((unsigned long long)(blockIdx.x / ((uint32_t)P.n_cu > 0u ? (uint32_t)P.n_cu : gridDim.x)) << 32);
             d[1] = __builtin_readcyclecounter() - t_start;
-            d[2] = heavy ? 1ull : 0ull;
+            d[2] = (heavy ? 1ull : 0ull) | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8) | ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15u) << 40);   // | HW_ID << 8 | XCC_ID << 40 (tools/gpu_pool_simd.py)
             d[3] = Wv.n_own;
             d[4] = dbg_march_iters;
             d[5] = dbg_passes;
