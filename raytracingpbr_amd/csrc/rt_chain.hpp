@@ -116,11 +116,11 @@ RT_D void chain_steps_impl(const Params& P, int steps) {
                     if (trk_ok) {
                         int it = 1;
 #ifdef RT_DEBUG_PHASE
-                        const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 1 << 20, it);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
                         dbg_form[form]++;
                         dbg_steps[form] += (unsigned)it;
 #else
-                        tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 1 << 20, it);
+                        tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
 #endif
                     } else if (L.state == ST_MARCH) {
                         march_step_src<KIND, NOBJ, SIG>(P, L);

@@ -238,6 +238,11 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         if (chain_on && chain > 3.0 * bulk && n_heavy > 0u) {
             const double T = chain * 1.15, thr_c = thr > chain / 8.0 ? thr : chain / 8.0;
             const uint32_t max_w = chain_on < 2048u ? chain_on : 2048u;
+            // (round 5, after the lean loops lost a third of their instructions: a wave of ONE pixel runs them nearly all the time,
+            // 610-720 cycles per step; a wave of two or three iterates in whatever form its lanes can share — per-wave records at
+            // 768x432: 820-1000 cycles per lane-step, the three-pixel waves ended at 45-56 Mcycles, the heaviest pixel alone at 36 —
+            // so a wave of several pixels is loaded to 1 / 1.45 of the limit)
+            const double multi_x = 1.45;
             uint32_t wv = 0, cnt = 0, pos = 0;
             double load = 0.0;
             bool full = false;
@@ -246,7 +251,7 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
                 if (c <= thr_c) break;
                 for (uint32_t i = 0; i < h[j]; i++) {
                     double add = c;
-                    if (cnt > 0u && (load + add > T || cnt >= 8u)) {
+                    if (cnt > 0u && ((load + add) * multi_x > T || cnt >= 8u)) {
                         wv++;
                         plan->chain_start[wv] = pos;          // (closes the previous wave)
                         if (wv >= max_w) { full = true; break; }

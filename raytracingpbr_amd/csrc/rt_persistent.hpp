@@ -205,6 +205,30 @@ RT_D float march_update_src(const Params& P, Lane& L, int idx, float dist) {
     L.state = done ? (hit ? ST_HIT : ST_MISS) : L.state;
     return s_new;
 }
+// The same iteration inside a lean loop: the lane's L.idx already is the object (IDX = false: no write), and when the
+// over-relaxation of the raycast is over — W1: every marching lane has w == 1, the caller checked — the fallback test cannot
+// fire and s = 1.0f * dist IS dist: nine instructions of bookkeeping less per step, same values (src/scene.py:67-78).
+template <bool W1, bool IDX>
+RT_D float march_update_src_lean(const Params& P, Lane& L, int idx, float dist) {
+    if constexpr (!W1) {
+        const int keep = L.idx;
+        const float s_new = march_update_src(P, L, idx, dist);
+        if constexpr (!IDX) L.idx = keep;
+        return s_new;
+    } else {
+        if constexpr (IDX) L.idx = idx;
+        L.dist = dist;
+        L.n_steps++;
+        L.steps_left--;
+        // (L.s is only read by the fallback test, which needs w > 1: dead for the rest of this raycast)
+        L.t += dist;
+        L.o = fma3(dist, L.d, L.o);
+        const bool hit = dist < L.t * P.cfg.hit_eps;
+        const bool done = (hit | (L.t >= P.cfg.max_dis)) | (L.steps_left == 0);
+        L.state = done ? (hit ? ST_HIT : ST_MISS) : L.state;
+        return dist;
+    }
+}
 template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
 RT_D void march_step_src(const Params& P, Lane& L) {
     int idx;
@@ -227,6 +251,11 @@ RT_D void march_step_src(const Params& P, Lane& L) {
 // One VGPR of state per lane (lb; <= 0 = "needs a full evaluation"); the tracked object is L.idx.
 RT_D float track_eps(const Params& P, vec3 o) {
     return 1.9073486328125e-06f * (((fabs_(o.x) + fabs_(o.y)) + fabs_(o.z)) + P.cull_extent);
+}
+// the allowance of a whole lean loop entered at o with the bound lb (see march_fast_src_obj): every position of the loop lies
+// within lb of o, |p|_1 within 2 lb of |o|_1
+RT_D float track_eps_loop(const Params& P, vec3 o, float lb) {
+    return 1.9073486328125e-06f * ((((fabs_(o.x) + fabs_(o.y)) + fabs_(o.z)) + P.cull_extent) + 2.0f * fmax_(lb, 0.0f));
 }
 // after a step of length s: the next position is |s| |d| away (|d| <= 1 + 2^-20); a quarter of eps covers the rounding
 // of the three coordinates (<= ulp(|p|) = eps / 16) and of the two roundings in this update (<= eps / 32 each)
@@ -303,16 +332,21 @@ RT_D void march_step_src_tracked(const Params& P, Lane& L, Trk& T, bool can, uns
 // whatever it is, so the length of the critical pixel's chain in time is (steps) x (instructions per iteration) x 6
 // cycles: this loop is what shortens it.  Runs until a lane fails its bound (it then waits for the wave's next full
 // evaluation, lb <= 0), a lane finishes its raycast, or max_it steps were taken; returns the steps taken.
-template <int KIND, int NOBJ, uint32_t SIG, int I, bool TWO = false>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
+template <int KIND, int NOBJ, uint32_t SIG, int I, bool TWO = false, bool W1 = false>      // I >= 0: object I of the unrolled table; I < 0: object k of the run-time table
 RT_D int march_fast_src_obj(const Params& P, Lane& L, Trk& T, int k, int max_it, int* why = nullptr) {
     float& lb = T.lb2;
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
     const unsigned long long mm = __ballot(marching);
     int it = 0;
+    unsigned long long fail = 0ull;
+    // ONE rounding allowance for the whole loop (a lone wave pays ~6.5 cycles for every instruction of its chain, and the allowance
+    // took five of them per step): the loop only goes on while lb > 0 and every step takes at least |s| off lb, so the path marched
+    // in here stays below the lb the lane came with and |p|_1 grows by less than sqrt(3) (1 + 2^-20) times that: 2 lb is on the safe
+    // side.  A larger allowance only ends the loop earlier (the full evaluation takes over): results are unchanged.
+    const float eps = track_eps_loop(P, L.o, lb);
     for (;;) {
         asm volatile("" : "+s"(tab));
-        const float eps = track_eps(P, L.o);
         float dk;
         if constexpr (I >= 0) {
             const ObjM o = load_obj<SIG, (I >= 0 ? I : 0)>(tab);
@@ -322,35 +356,40 @@ RT_D int march_fast_src_obj(const Params& P, Lane& L, Trk& T, int k, int max_it,
             dk = fabs_(signed_distance<KIND>(P, o, L.o));
         }
         const bool ok = marching & (lb > dk + eps) & (!P.cfg.nearest_init | (dk < P.cfg.max_dis));
+        // (the loop's exit as lane masks in scalar registers: a lane goes on iff it stepped and still marches; written with bool
+        // selects the compiler materialised four 0/1 VGPRs and a dozen scalar instructions per step of this loop — and the vote
+        // on `ok` is put together from the votes on its comparisons: a vote on the combined flag goes through a 0/1 VGPR)
+        const unsigned long long okm = mm & __builtin_amdgcn_ballot_w64(lb > dk + eps) & (P.cfg.nearest_init ? __builtin_amdgcn_ballot_w64(dk < P.cfg.max_dis) : ~0ull);
+        fail = mm & ~okm;
         if (ok) {
-            const float s_new = march_update_src(P, L, k, dk);
+            const float s_new = march_update_src_lean<W1, false>(P, L, k, dk);      // (every marching lane's L.idx is k already)
             lb = track_decay(lb, s_new, eps);
             if constexpr (TWO) T.lb3 = track_decay(T.lb3, s_new, eps);
         }
         it++;
-        // (the loop's exit as lane masks in scalar registers: a lane goes on iff it stepped and still marches; written with bool
-        // selects the compiler materialised four 0/1 VGPRs and a dozen scalar instructions per step of this loop)
-        const unsigned long long live = __ballot(ok) & __ballot(L.state == ST_MARCH);
-        if ((live != mm) | (it >= max_it)) {
+        const unsigned long long live = okm & __builtin_amdgcn_ballot_w64(L.state == ST_MARCH);
+        if ((live != mm) | (max_it > 0 && it >= max_it)) {      // (max_it <= 0: no cap — a literal at the call, the test folds away)
 #if RT_DEBUG_PHASE == 4
-            if (why) *why = __any(marching & !ok) ? 2 : (live != mm ? 1 : 0);      // bound failed / a raycast ended / max_it
+            if (why) *why = fail ? 2 : (live != mm ? 1 : 0);      // bound failed / a raycast ended / max_it
 #endif
-            if (marching & !ok) lb = -1.0f;
             break;
         }
     }
+    // a lane whose bound failed in the last step waits for the wave's next full evaluation (from the scalar mask, after the loop:
+    // written as a select on `ok` the compiler re-evaluates it in every iteration)
+    if ((fail >> (threadIdx.x & 63u)) & 1ull) lb = -1.0f;
     return it;
 }
-template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
+template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false, bool W1 = false>
 RT_D int march_fast_src(const Params& P, Lane& L, Trk& lb, int k, int max_it, int* why = nullptr) {
     int it = 0;
     if constexpr (NOBJ > 0) {
         static_for<NOBJ, 1>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
-            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i, TWO>(P, L, lb, i, max_it, why);
+            if (k == i) it = march_fast_src_obj<KIND, NOBJ, SIG, i, TWO, W1>(P, L, lb, i, max_it, why);
         });
     } else {
-        it = march_fast_src_obj<KIND, NOBJ, SIG, -1, TWO>(P, L, lb, k, max_it, why);
+        it = march_fast_src_obj<KIND, NOBJ, SIG, -1, TWO, W1>(P, L, lb, k, max_it, why);
     }
     return it;
 }
@@ -359,15 +398,16 @@ RT_D int march_fast_src(const Params& P, Lane& L, Trk& lb, int k, int max_it, in
 // are evaluated, the nearer one (the lower index on a tie, as nearest() resolves it: objects are visited in index order with a
 // strict `<`) is exactly what nearest() returns while lb3 > min + eps.  lb2 is re-derived on the way (the other object of the
 // pair, or lb3): when the second surface recedes the one-object loop can take over again without a full evaluation.
-template <int KIND, int NOBJ, uint32_t SIG, int A, int B>      // A >= 0: objects A < B of the unrolled table; A < 0: objects a, b of the run-time table
+template <int KIND, int NOBJ, uint32_t SIG, int A, int B, bool W1 = false>      // A >= 0: objects A < B of the unrolled table; A < 0: objects a, b of the run-time table
 RT_D int march_fast2_src_pair(const Params& P, Lane& L, Trk& T, int a, int b, int max_it) {
     ObjTab tab = obj_table();
     const bool marching = L.state == ST_MARCH;
     const unsigned long long mm = __ballot(marching);
     int it = 0;
+    unsigned long long fail = 0ull;
+    const float eps = track_eps_loop(P, L.o, T.lb3);      // (as in the one-object loop: the path marched in here stays below lb3)
     for (;;) {
         asm volatile("" : "+s"(tab));
-        const float eps = track_eps(P, L.o);
         float dA, dB;
         if constexpr (A >= 0) {
             const ObjM oa = load_obj<SIG, (A >= 0 ? A : 0)>(tab);
@@ -384,22 +424,22 @@ RT_D int march_fast2_src_pair(const Params& P, Lane& L, Trk& T, int a, int b, in
         const float d = lt ? dB : dA;
         const float d_other = lt ? dA : dB;
         const bool ok = marching & (T.lb3 > d + eps) & (!P.cfg.nearest_init | (d < P.cfg.max_dis));
+        const unsigned long long okm = mm & __builtin_amdgcn_ballot_w64(T.lb3 > d + eps) & (P.cfg.nearest_init ? __builtin_amdgcn_ballot_w64(d < P.cfg.max_dis) : ~0ull);
+        fail = mm & ~okm;
         if (ok) {
-            const float s_new = march_update_src(P, L, lt ? b : a, d);
+            const float s_new = march_update_src_lean<W1, true>(P, L, lt ? b : a, d);
             T.lb2 = track_decay(fmin_(d_other - eps, T.lb3), s_new, eps);
             T.lb3 = track_decay(T.lb3, s_new, eps);
             T.k2 = lt ? a : b;
         }
         it++;
-        const unsigned long long live = __ballot(ok) & __ballot(L.state == ST_MARCH);
-        if ((live != mm) | (it >= max_it)) {
-            if (marching & !ok) T.lb3 = T.lb2 = -1.0f;
-            break;
-        }
+        const unsigned long long live = okm & __builtin_amdgcn_ballot_w64(L.state == ST_MARCH);
+        if ((live != mm) | (max_it > 0 && it >= max_it)) break;
     }
+    if ((fail >> (threadIdx.x & 63u)) & 1ull) T.lb3 = T.lb2 = -1.0f;
     return it;
 }
-template <int KIND, int NOBJ, uint32_t SIG>
+template <int KIND, int NOBJ, uint32_t SIG, bool W1 = false>
 RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max_it) {      // a < b, wave-uniform
     int it = 0;
     if constexpr (NOBJ > 0) {
@@ -409,13 +449,13 @@ RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max
                 static_for<NOBJ, 1>([&](auto Ib) {
                     constexpr int B = decltype(Ib)::value;
                     if constexpr (A < B) {
-                        if (b == B) it = march_fast2_src_pair<KIND, NOBJ, SIG, A, B>(P, L, T, A, B, max_it);
+                        if (b == B) it = march_fast2_src_pair<KIND, NOBJ, SIG, A, B, W1>(P, L, T, A, B, max_it);
                     }
                 });
             }
         });
     } else {
-        it = march_fast2_src_pair<KIND, NOBJ, SIG, -1, -1>(P, L, T, a, b, max_it);
+        it = march_fast2_src_pair<KIND, NOBJ, SIG, -1, -1, W1>(P, L, T, a, b, max_it);
     }
     return it;
 }
@@ -439,11 +479,16 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
     const int first = (int)__builtin_ctzll(mm);
     steps = 1;
     const bool two = TWO && P.src_track >= 2;
+    // the raycasts that make a launch long lose their over-relaxation within a few steps (w: 1.6 -> 1 at the first overshoot) and
+    // then march hundreds of steps with w == 1: the lean loops have an instance without the relaxation bookkeeping for that
+    // (kernels that keep both bounds only — the chain kernel and the split march; the fused pool kernel has no room for more code)
+    const bool w1 = TWO && __ballot(marching & (L.w != 1.0f)) == 0ull;
     // (one bound only: any valid lb2 tries the lean loop, as round 4 did)
     if (__ballot(marching & (T.lb2 > (two ? L.dist : 0.0f))) == mm) {
         const int k0 = __builtin_amdgcn_readlane(L.idx, first);
         if (__ballot(marching && L.idx != k0) == 0ull) {
-            steps = march_fast_src<KIND, NOBJ, SIG, TWO>(P, L, T, k0, max_it, why);
+            if (TWO && w1) steps = march_fast_src<KIND, NOBJ, SIG, TWO, TWO>(P, L, T, k0, max_it, why);
+            else steps = march_fast_src<KIND, NOBJ, SIG, TWO>(P, L, T, k0, max_it, why);
             return 1;
         }
     }
@@ -453,7 +498,8 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
         const int key0 = __builtin_amdgcn_readlane(key, first);
         if (__ballot(marching && key != key0) == 0ull) {
             if (marching) T.lb2 = -1.0f;      // (re-derived by the loop's first step)
-            steps = march_fast2_src<KIND, NOBJ, SIG>(P, L, T, key0 & 255, key0 >> 8, max_it);
+            if (w1) steps = march_fast2_src<KIND, NOBJ, SIG, true>(P, L, T, key0 & 255, key0 >> 8, max_it);
+            else steps = march_fast2_src<KIND, NOBJ, SIG>(P, L, T, key0 & 255, key0 >> 8, max_it);
             return 2;
         }
     }

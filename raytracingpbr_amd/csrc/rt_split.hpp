@@ -293,7 +293,7 @@ RT_D void src_march_impl(const Params& P) {
                     const uint32_t steps_before = L.n_steps;
 #endif
                     int it = 1;
-                    const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 1 << 20, it);
+                    const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
                     (void)form;
 #ifdef RT_DEBUG_PHASE
                     if (form == 1) { dbg_fast_calls++; dbg_fast_steps += (unsigned)it; }
