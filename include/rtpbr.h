@@ -288,6 +288,13 @@ int rtpbr_sync(rtpbr_ctx* ctx);
 int rtpbr_read_buffer(rtpbr_ctx* ctx, int which, void* dst, size_t nbytes);
 int rtpbr_write_buffer(rtpbr_ctx* ctx, int which, const void* src, size_t nbytes);
 
+/* Page-locked host memory for the destination of rtpbr_read_buffer(): a host that shows every frame (src/main.py:62-64 hands
+ * image_pixels to the window once per render()) reads into the SAME buffer again and again, and a page-locked one takes the copy
+ * at the link's rate without the driver's staging.  Plain memory works as before; this is an optimisation the caller opts into.
+ * Freed by rtpbr_host_free() or with the context. */
+int rtpbr_host_alloc(rtpbr_ctx* ctx, size_t nbytes, void** ptr);
+int rtpbr_host_free(rtpbr_ctx* ctx, void* ptr);
+
 /* Multi-GPU gather support.  pack: copy this rank's tiles of image_buffer, tile-major,
  * into a DEVICE buffer of rtpbr_packed_bytes() bytes (all ranks get the same padded size
  * so one RCCL gather moves them).  unpack: scatter a packed buffer that belongs to rank

@@ -22,7 +22,7 @@ HIP_LIB_PATH = os.environ.get("RTPBR_HIP_LIB") or os.path.join(_HERE, "csrc", "l
 ENTRY_POINTS = [
     "create", "destroy", "last_error", "backend", "set_config", "set_scene", "get_scene",
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",
-    "read_buffer", "write_buffer", "packed_bytes", "pack_tiles", "unpack_tiles",
+    "read_buffer", "write_buffer", "host_alloc", "host_free", "packed_bytes", "pack_tiles", "unpack_tiles",
     "get_counters", "get_counter", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
     "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info",
 ]
@@ -59,6 +59,8 @@ class CApi:
             "sync": (C.c_int, [p]),
             "read_buffer": (C.c_int, [p, C.c_int, p, C.c_size_t]),
             "write_buffer": (C.c_int, [p, C.c_int, p, C.c_size_t]),
+            "host_alloc": (C.c_int, [p, C.c_size_t, C.POINTER(p)]),
+            "host_free": (C.c_int, [p, p]),
             "packed_bytes": (C.c_int, [p, C.POINTER(C.c_size_t)]),
             "pack_tiles": (C.c_int, [p, p]),
             "unpack_tiles": (C.c_int, [p, p, C.c_int]),

@@ -92,6 +92,8 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     c->jit_mod = nullptr;
     (void)hipFree(c->work_counter);
     (void)hipFree(c->team_counter);
+    for (void* hb : c->host_blocks) (void)hipHostFree(hb);
+    c->host_blocks.clear();
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
@@ -805,6 +807,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                     // four waves per SIMD: with more the youngest starve (the arbiter serves the oldest wave first) and end last;
                     // measured at 1080p: 2 / 3 / 4 / 5 / 8 waves = 0.53 / 0.51 / 0.51 / 0.55 / 0.59 ms per launch
                     if (mper > 4) mper = 4;
+                    // (small frames are all tail: two waves per SIMD — 2 / 3 / 4 at 640x360 0.230 / 0.236 / 0.240 ms per launch, 768x432
+                    // 0.258 / 0.261 / 0.270, 960x540 0.287 / 0.289 / 0.292; no difference from 1024x576 on)
+                    if ((long long)P.np <= 600000 && mper > 2) mper = 2;
                     if (c->waves_per_cu > 0) mper = (c->waves_per_cu + 3) / 4;
                     long long mgrid = (long long)mper * c->n_cu;
                     const long long need = ((long long)P.np + 255) / 256;
@@ -986,6 +991,29 @@ extern "C" int rtpbr_read_buffer(rtpbr_ctx* c, int which, void* dst, size_t nbyt
     HIP_TRY(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTPBR_OK;
+}
+
+extern "C" int rtpbr_host_alloc(rtpbr_ctx* c, size_t nbytes, void** ptr) {
+    if (!c || !ptr || nbytes == 0) return fail(RTPBR_EINVAL, "rtpbr_host_alloc: context, size and result pointer are required");
+    if (int r = set_dev(c)) return r;
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
+    c->host_blocks.push_back(p);
+    *ptr = p;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_host_free(rtpbr_ctx* c, void* ptr) {
+    if (!c || !ptr) return fail(RTPBR_EINVAL, "rtpbr_host_free: context and pointer are required");
+    for (size_t i = 0; i < c->host_blocks.size(); i++)
+        if (c->host_blocks[i] == ptr) {
+            if (int r = set_dev(c)) return r;
+            HIP_TRY(hipStreamSynchronize(c->stream));      // (a copy into it may be in flight)
+            c->host_blocks.erase(c->host_blocks.begin() + (long)i);
+            HIP_TRY(hipHostFree(ptr));
+            return RTPBR_OK;
+        }
+    return fail(RTPBR_EINVAL, "rtpbr_host_free: not a block of this context");
 }
 
 extern "C" int rtpbr_write_buffer(rtpbr_ctx* c, int which, const void* src, size_t nbytes) {

@@ -141,6 +141,7 @@ struct rtpbr_ctx {
     int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)
     uint32_t* cost_buffer = nullptr;   // np x u32
     unsigned int* team_counter = nullptr;   // 1024 counters x 64 bytes (split march kernel)
+    std::vector<void*> host_blocks;         // page-locked host memory handed out by rtpbr_host_alloc (freed with the context)
     uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
     size_t march_np = 0;
     int src_chain = 1;            // src/ form, fused launches: the plan's chain set runs in the chain kernel beside the pool kernel (rt_chain.hpp)

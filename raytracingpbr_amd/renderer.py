@@ -117,6 +117,24 @@ class Renderer:
         self.api.call("read_buffer", self._ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
         return out
 
+    def host_array(self, which):
+        """A page-locked numpy array of a buffer's shape (rtpbr_host_alloc): the destination a host that shows every frame reads
+        into again and again — ``r.read_into(BUF_IMAGE_PIXELS, a)``.  Lives as long as the renderer."""
+        shape, dt = self._shape(which)
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        ptr = C.c_void_p()
+        self.api.call("host_alloc", self._ctx, n, C.byref(ptr))
+        buf = (C.c_char * n).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    def read_into(self, which, out):
+        """field.to_numpy() into an array the caller keeps (any C-contiguous array of the buffer's shape and dtype)."""
+        shape, dt = self._shape(which)
+        if out.shape != tuple(shape) or out.dtype != np.dtype(dt) or not out.flags.c_contiguous:
+            raise ValueError(f"expected a C-contiguous {dt} array of shape {shape}")
+        self.api.call("read_buffer", self._ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
     def _write(self, which, arr):
         shape, dt = self._shape(which)
         a = np.ascontiguousarray(arr, dtype=dt)

@@ -371,6 +371,29 @@ def test_checkpoint_resume_through_write_buffer():
     assert np.array_equal(bits(c.image_buffer), bits(a.image_buffer))
 
 
+def test_read_into_page_locked_host_buffer():
+    """rtpbr_host_alloc / read_into: the page-locked destination holds the same bits as a fresh read; foreign pointers are refused."""
+    from raytracingpbr_amd.renderer import BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS
+    case = case_by_name("src_persistent")
+    r = Renderer(case.scene, case.cfg)
+    case.setup(r)
+    pinned = r.host_array(BUF_IMAGE_PIXELS)
+    acc = r.host_array(BUF_IMAGE_BUFFER)
+    for _ in range(3):
+        r.sample(4)
+        r.post_process()
+        r.read_into(BUF_IMAGE_PIXELS, pinned)
+        r.read_into(BUF_IMAGE_BUFFER, acc)
+        assert np.array_equal(bits(pinned), bits(r.image_pixels)) and np.array_equal(bits(acc), bits(r.image_buffer))
+    with pytest.raises(ValueError):
+        r.read_into(BUF_IMAGE_PIXELS, np.zeros((3, 3), np.float32))
+    junk = (C.c_char * 64)()
+    with pytest.raises(RtpbrError):
+        r.api.call("host_free", r._ctx, C.cast(junk, C.c_void_p))
+    r.api.call("host_free", r._ctx, C.c_void_p(pinned.ctypes.data))
+    r.close()                      # (frees `acc` with the context)
+
+
 def test_refresh_semantics():
     case = case_by_name("src_persistent")
     r = Renderer(case.scene, case.cfg)
