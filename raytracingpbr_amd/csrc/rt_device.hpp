@@ -264,10 +264,10 @@ RT_D float sd_box(vec3 l, float sx, float sy, float sz, float rho) {
     vec3 u = mk(qx + fabs_(qx), qy + fabs_(qy), qz + fabs_(qz));
 #if RT_FAST_MATH      // (the root is the distance to the box's core: never large where it matters — the bare instruction)
     const float len = 0.5f * sqrt_shape_(dot(u, u), false);
-#else
-    const float len = sqrt_quarter_(dot(u, u));
-#endif
     return (len + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
+#else
+    return sqrt_quarter_add_(dot(u, u), fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;      // (root + addend in one fma: rt_math.hpp)
+#endif
 #else
     vec3 m = mk(fmax_(qx, 0.0f), fmax_(qy, 0.0f), fmax_(qz, 0.0f));
     return (sqrt_(dot(m, m)) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f)) - rho;
@@ -280,15 +280,19 @@ RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, floa
     if (KIND == KIND_BUNNY) return sd_bunny(P.bunny, l);
     switch (type) {
         case RTPBR_SHAPE_SPHERE:
+#if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT)
             return (sx > RT_BIG_EXTENT ? sqrt_big_sphere_(dot(l, l), sx) : sqrt_shape_(dot(l, l), false)) - sx;
+#else
+            return sqrt_add_(dot(l, l), -sx);
+#endif
         case RTPBR_SHAPE_BOX:
             return sd_box(l, sx, sy, sz, P.cfg.box_round);
         case RTPBR_SHAPE_CYLINDER: {
             const bool big = sx > RT_BIG_EXTENT || sy > RT_BIG_EXTENT;
-            float r = sqrt_shape_(fma_(l.z, l.z, l.x * l.x), big);
-            float dx = fabs_(r) - sx, dy = fabs_(l.y) - sy;
+            // (|r| - sx with r a root: r >= +0, the abs is the identity; both roots take their addend in the root's own fma)
+            float dx = sqrt_shape_add_(fma_(l.z, l.z, l.x * l.x), big, -sx), dy = fabs_(l.y) - sy;
             float mx = fmax_(dx, 0.0f), my = fmax_(dy, 0.0f);
-            return fmin_(fmax_(dx, dy), 0.0f) + sqrt_shape_(fma_(my, my, mx * mx), big);
+            return sqrt_shape_add_(fma_(my, my, mx * mx), big, fmin_(fmax_(dx, dy), 0.0f));
         }
         case RTPBR_SHAPE_CONE: {
             float q = sqrt_shape_(fma_(l.z, l.z, l.x * l.x), sy > RT_BIG_EXTENT);
@@ -499,7 +503,7 @@ RT_D bool nearest_boxes_lazy(const Params& P, vec3 p, int& idx, float& best) {
     if (__any(suspect)) return false;
 #endif
     const bool core = !(pmx > 0.0f);
-    float d = core ? rho - pmx : fabs_(sqrt_quarter_(k1) - rho);
+    float d = core ? rho - pmx : fabs_(sqrt_quarter_add_(k1, -rho));
     if (P.cfg.nearest_init && !(d < P.cfg.max_dis)) {   // src/ form: the search starts from (0, MAX_DIS)
         d = P.cfg.max_dis;
         idx = 0;

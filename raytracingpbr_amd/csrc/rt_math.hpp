@@ -113,6 +113,40 @@ RT_HD float sqrt_quarter_(float x) {
     return __builtin_sqrtf(x * 0.25f);
 #endif
 }
+// sqrt_(x) + c and sqrt_quarter_(x) + c in one rounding less to ISSUE, not to compute: the root's power-of-two post-scaling is exact
+// (no underflow: the root of the smallest denormal is 2^-74.5), so fma(y, 2^-16, c) rounds exactly the sum sqrt_(x) + c that the two
+// separate instructions round — one instruction instead of two behind every root whose next operation is an addition (a sphere's
+// `- r`, a box's `+ min(max3 q, 0)`, a cylinder's `- r` and `+ min(..)`, the lazy box search's `- rho`).
+RT_HD float sqrt_add_(float x, float c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !(RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT))
+    float xs = x * 4294967296.0f;
+    float y = __builtin_amdgcn_sqrtf(xs);
+    float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    float rm = __builtin_fmaf(-ym, y, xs);
+    float rp = __builtin_fmaf(-yp, y, xs);
+    y = (0.0f >= rm) ? ym : y;
+    y = (0.0f < rp) ? yp : y;
+    return __builtin_fmaf(y, 1.52587890625e-05f, c);
+#else
+    return sqrt_(x) + c;
+#endif
+}
+RT_HD float sqrt_quarter_add_(float x, float c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !(RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT))
+    float xs = x * 1073741824.0f;
+    float y = __builtin_amdgcn_sqrtf(xs);
+    float ym = __builtin_bit_cast(float, __builtin_bit_cast(int, y) - 1);
+    float yp = __builtin_bit_cast(float, __builtin_bit_cast(int, y) + 1);
+    float rm = __builtin_fmaf(-ym, y, xs);
+    float rp = __builtin_fmaf(-yp, y, xs);
+    y = (0.0f >= rm) ? ym : y;
+    y = (0.0f < rp) ? yp : y;
+    return __builtin_fmaf(y, 1.52587890625e-05f, c);
+#else
+    return sqrt_quarter_(x) + c;
+#endif
+}
 RT_HD float sqrt_ieee_(float x) { return __builtin_sqrtf(x); }
 // The root inside a shape's distance.  Exact flavour: sqrt_.  Tolerance flavour: the correction step of sqrt_fast_ only where
 // the root cancels against something LARGE (`big`: the shape's radius / half-height above RT_BIG_EXTENT — the 100-unit ground
@@ -138,6 +172,15 @@ RT_HD float sqrt_shape_(float x, bool big) {
 #endif
     (void)big;
     return sqrt_(x);
+}
+// sqrt_shape_(x, big) + c (exact flavour: the fused form above)
+RT_HD float sqrt_shape_add_(float x, bool big, float c) {
+#if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT) && defined(__HIP_DEVICE_COMPILE__)
+    return sqrt_shape_(x, big) + c;
+#else
+    (void)big;
+    return sqrt_add_(x, c);
+#endif
 }
 RT_HD float length(vec3 a) { return sqrt_(dot(a, a)); }
 RT_HD vec3 normalize(vec3 a) {
