@@ -20,7 +20,7 @@ r.sync()
 tr, tot, n = r.last_sample_ms()
 db = np.ascontiguousarray(r.diff_buffer).view(np.uint64).reshape(-1)[4096 * 8:(4096 + 8192) * 8].reshape(-1, 8)
 db = db[db[:, 7] == 0x7654321]
-cls = (db[:, 0] >> 32).astype(int); life = db[:, 1] / 1e6; heavy = db[:, 2] == 1; own = db[:, 3]; iters = db[:, 4]; passes = db[:, 5]; steps = db[:, 6]
+cls = (db[:, 0] >> 32).astype(int); life = db[:, 1] / 1e6; heavy = (db[:, 2] & 1) == 1; own = db[:, 3]; iters = db[:, 4]; passes = db[:, 5]; steps = db[:, 6]
 q = lambda a: [round(float(x), 1) for x in np.percentile(a, [0, 10, 50, 90, 99, 100])]
 out = {"kernel_ms": round(tr, 3), "waves": len(db), "heavy_waves": int(heavy.sum())}
 lt = ~heavy
