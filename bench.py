@@ -296,6 +296,21 @@ def frame_latency(a, device, W=768, H=432, frames=200):
         r.render()
         r.read_into(BUF_IMAGE_PIXELS, pinned)
     dt = time.perf_counter() - t0
+    # ... and handed over WITHOUT stalling the device (round 6: rtpbr_read_buffer_async): frame k's copy into one of two
+    # page-locked buffers is in flight while frame k+1 is sampled; the host takes delivery of frame k-1 each iteration
+    pinned2 = [pinned, r.host_array(BUF_IMAGE_PIXELS)]
+    prev = r.read_async(BUF_IMAGE_PIXELS, pinned2[1])
+    r.read_wait(prev)
+    t0 = time.perf_counter()
+    prev = None
+    for k in range(frames):
+        r.render()
+        t = r.read_async(BUF_IMAGE_PIXELS, pinned2[k & 1])
+        if prev is not None:
+            r.read_wait(prev)                 # frame k-1 is in host memory now
+        prev = t
+    r.read_wait(prev)
+    dt_pipe = time.perf_counter() - t0
     t0 = time.perf_counter()
     for _ in range(frames):
         r.render()
@@ -308,6 +323,9 @@ def frame_latency(a, device, W=768, H=432, frames=200):
                         f"one displayed frame of the reference (src/renderer.py:25-32, src/main.py:62-64), {frames} frames",
             "ms_per_frame": round(dt / frames * 1e3, 4), "frames_per_s": round(frames / dt, 1),
             "ms_per_frame_fresh_host_array": round(dt_fresh / frames * 1e3, 4),
+            "ms_per_frame_pipelined": round(dt_pipe / frames * 1e3, 4), "frames_per_s_pipelined": round(frames / dt_pipe, 1),
+            "pipelined": "rtpbr_read_buffer_async into two page-locked buffers: frame k's copy overlaps frame k+1's sample kernels, every frame is delivered to the host (one frame later); "
+                         "a consumer on the GPU takes rtpbr_buffer_device_ptr and pays device_ms_per_frame",
             "host_buffer": "ms_per_frame reads image_pixels into one page-locked host buffer (rtpbr_host_alloc) every frame; ms_per_frame_fresh_host_array allocates a numpy array per frame (round 4's figure)",
             "device_ms_per_frame": round(dt_dev / frames * 1e3, 4), "sample_kernels_ms": round(tr, 4),
             "readback_bytes_per_frame": int(np.asarray(px).nbytes), "run_time_kernels": split,

@@ -295,6 +295,27 @@ int rtpbr_write_buffer(rtpbr_ctx* ctx, int which, const void* src, size_t nbytes
 int rtpbr_host_alloc(rtpbr_ctx* ctx, size_t nbytes, void** ptr);
 int rtpbr_host_free(rtpbr_ctx* ctx, void* ptr);
 
+/* Handing a frame over WITHOUT stalling the device (round 6).  The reference's window takes image_pixels on the device
+ * (`canvas.set_image(image_pixels)`, src/main.py:64: the frame never visits the host) and its loop goes straight on to the
+ * next render(); rtpbr_read_buffer() above is the blocking `field.to_numpy()`.  Two more ways out:
+ *
+ * rtpbr_buffer_device_ptr: the DEVICE address and size of a buffer — zero copy for a consumer on the same GPU (display
+ *   interop, a video encoder, a torch tensor through __cuda_array_interface__).  The consumer orders itself behind the
+ *   context's work with rtpbr_get_stream() (or calls rtpbr_sync()); the address stays valid until rtpbr_set_config()
+ *   changes the resolution or the context is destroyed, and the next rtpbr_post_process() / rtpbr_sample() overwrites
+ *   the contents, as the reference's next render() does.
+ *
+ * rtpbr_read_buffer_async: enqueue the copy of a buffer into PAGE-LOCKED host memory (a block of rtpbr_host_alloc; EINVAL
+ *   otherwise — a pageable destination would make the copy synchronous) behind everything enqueued on the context so
+ *   far, on a copy stream of its own, and return a ticket at once.  The context's later work does NOT wait for the copy —
+ *   frame k's read-back overlaps frame k+1's sample kernels — except the first call that would overwrite the buffer
+ *   being read (the next rtpbr_post_process() for image_pixels): that one is ordered behind the copy on the device, the
+ *   host still does not block.  rtpbr_read_wait(ticket) blocks the HOST until that copy has landed in `dst`.  Up to 8
+ *   reads may be outstanding; taking a 9th ticket first waits for the oldest. */
+int rtpbr_buffer_device_ptr(rtpbr_ctx* ctx, int which, void** device_ptr, size_t* nbytes);
+int rtpbr_read_buffer_async(rtpbr_ctx* ctx, int which, void* dst, size_t nbytes, int* ticket);
+int rtpbr_read_wait(rtpbr_ctx* ctx, int ticket);
+
 /* Multi-GPU gather support.  pack: copy this rank's tiles of image_buffer, tile-major,
  * into a DEVICE buffer of rtpbr_packed_bytes() bytes (all ranks get the same padded size
  * so one RCCL gather moves them).  unpack: scatter a packed buffer that belongs to rank

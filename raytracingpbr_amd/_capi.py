@@ -22,7 +22,8 @@ HIP_LIB_PATH = os.environ.get("RTPBR_HIP_LIB") or os.path.join(_HERE, "csrc", "l
 ENTRY_POINTS = [
     "create", "destroy", "last_error", "backend", "set_config", "set_scene", "get_scene",
     "set_camera", "set_env", "set_tiles", "refresh", "sample", "post_process", "sync",
-    "read_buffer", "write_buffer", "host_alloc", "host_free", "packed_bytes", "pack_tiles", "unpack_tiles",
+    "read_buffer", "write_buffer", "host_alloc", "host_free", "buffer_device_ptr", "read_buffer_async", "read_wait",
+    "packed_bytes", "pack_tiles", "unpack_tiles",
     "get_counters", "get_counter", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
     "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info",
 ]
@@ -61,6 +62,9 @@ class CApi:
             "write_buffer": (C.c_int, [p, C.c_int, p, C.c_size_t]),
             "host_alloc": (C.c_int, [p, C.c_size_t, C.POINTER(p)]),
             "host_free": (C.c_int, [p, p]),
+            "buffer_device_ptr": (C.c_int, [p, C.c_int, C.POINTER(p), C.POINTER(C.c_size_t)]),
+            "read_buffer_async": (C.c_int, [p, C.c_int, p, C.c_size_t, C.POINTER(C.c_int)]),
+            "read_wait": (C.c_int, [p, C.c_int]),
             "packed_bytes": (C.c_int, [p, C.POINTER(C.c_size_t)]),
             "pack_tiles": (C.c_int, [p, p]),
             "unpack_tiles": (C.c_int, [p, p, C.c_int]),

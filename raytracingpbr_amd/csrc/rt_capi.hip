@@ -73,6 +73,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     if (!c) return RTPBR_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // (an asynchronous read-back may still be copying out of the buffers)
     (void)hipFree(c->image_buffer);
     (void)hipFree(c->image_pixels);
     (void)hipFree(c->ray_buffer);
@@ -94,6 +95,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->team_counter);
     for (void* hb : c->host_blocks) (void)hipHostFree(hb);
     c->host_blocks.clear();
+    c->host_sizes.clear();
     (void)hipFree(c->counters);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
@@ -103,6 +105,13 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
         (void)hipStreamSynchronize(c->stream2);
         (void)hipStreamDestroy(c->stream2);
     }
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    if (c->ev_read_ready) (void)hipEventDestroy(c->ev_read_ready);
+    for (hipEvent_t e : c->ev_read_done)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -159,6 +168,8 @@ extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
     if (realloc_buf) {
         size_t n = (size_t)cfg->width * cfg->height;
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        for (int& t : c->read_pending) t = -1;
         (void)hipFree(c->image_buffer);
         (void)hipFree(c->image_pixels);
         (void)hipFree(c->ray_buffer);
@@ -525,9 +536,23 @@ extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world
     return RTPBR_OK;
 }
 
+// A call that WRITES the buffers of `mask` (bit RTPBR_BUF_*) on the context's stream is ordered behind an asynchronous
+// read-back that still copies out of them (rtpbr_read_buffer_async) — on the device: the host does not block.
+int rt_order_after_reads(rtpbr_ctx* c, unsigned mask) {
+    for (int b = 0; b < 5; b++)
+        if (((mask >> b) & 1u) && c->read_pending[b] >= 0) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_read_done[c->read_pending[b] & 7], 0));
+            c->read_pending[b] = -1;
+        }
+    return RTPBR_OK;
+}
+enum : unsigned { W_IMAGE_BUFFER = 1u << RTPBR_BUF_IMAGE_BUFFER, W_IMAGE_PIXELS = 1u << RTPBR_BUF_IMAGE_PIXELS, W_RAY_BUFFER = 1u << RTPBR_BUF_RAY_BUFFER,
+                W_DIFF_BUFFER = 1u << RTPBR_BUF_DIFF_BUFFER, W_DIFF_PIXELS = 1u << RTPBR_BUF_DIFF_PIXELS };
+
 extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
     if (int r = set_dev(c)) return r;
+    if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER | W_DIFF_PIXELS)) return r;
     size_t n = (size_t)c->cfg.width * c->cfg.height;
     launch_refresh(c->image_buffer, c->ray_buffer, c->diff_buffer, c->diff_pixels, c->cfg.adaptive_sampling, n, c->stream);
     HIP_TRY(hipGetLastError());
@@ -600,6 +625,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
     if (n < 0) return fail(RTPBR_EINVAL, "n must be >= 0");
     if (int r = set_dev(c)) return r;
+    // (diff_buffer: instrumented builds write their per-wave records over it)
+    if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER)) return r;
     Params& P = c->P;
     P.cfg = c->cfg;
     P.cam.inv_w = 1.0f / (float)c->cfg.width;
@@ -749,6 +776,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                 P.heavy_own = c->heavy_own;
                 P.heavy_prio = c->heavy_prio;
                 P.src_track = c->src_track;
+                P.src_op = c->src_op;
                 P.leave_x8 = c->leave_x8;
                 P.tiny_own = c->tiny_own;
                 P.n_cu = c->n_cu;
@@ -951,6 +979,7 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
 extern "C" int rtpbr_post_process(rtpbr_ctx* c) {
     if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
     if (int r = set_dev(c)) return r;
+    if (int r = rt_order_after_reads(c, W_IMAGE_PIXELS | W_DIFF_BUFFER | W_DIFF_PIXELS)) return r;
     c->P.cfg = c->cfg;
     c->P.image_buffer = c->image_buffer;
     c->P.image_pixels = c->image_pixels;
@@ -965,6 +994,7 @@ extern "C" int rtpbr_sync(rtpbr_ctx* c) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (int r = set_dev(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));      // asynchronous read-backs have landed too
     // a gather enqueued earlier has run by now: what did the communicator make of it (any rank)?
     return rt_rccl_check_async(c);
 }
@@ -993,12 +1023,62 @@ extern "C" int rtpbr_read_buffer(rtpbr_ctx* c, int which, void* dst, size_t nbyt
     return RTPBR_OK;
 }
 
+// canvas.set_image(image_pixels), src/main.py:64: the consumer takes the frame where it is
+extern "C" int rtpbr_buffer_device_ptr(rtpbr_ctx* c, int which, void** device_ptr, size_t* nbytes) {
+    void* p;
+    size_t n;
+    if (int r = buf_ptr(c, which, &p, &n)) return r;
+    if (!device_ptr) return fail(RTPBR_EINVAL, "rtpbr_buffer_device_ptr: result pointer is required");
+    *device_ptr = p;
+    if (nbytes) *nbytes = n;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_read_buffer_async(rtpbr_ctx* c, int which, void* dst, size_t nbytes, int* ticket) {
+    void* p;
+    size_t n;
+    if (int r = buf_ptr(c, which, &p, &n)) return r;
+    if (!dst || !ticket || nbytes != n) return fail(RTPBR_EINVAL, "rtpbr_read_buffer_async: destination, ticket and the buffer's exact size are required");
+    bool pinned = false;
+    for (size_t i = 0; i < c->host_blocks.size() && !pinned; i++) {
+        const char* b = (const char*)c->host_blocks[i];
+        pinned = (const char*)dst >= b && (const char*)dst + n <= b + c->host_sizes[i];
+    }
+    if (!pinned) return fail(RTPBR_EINVAL, "rtpbr_read_buffer_async: the destination must lie inside a block of rtpbr_host_alloc (page-locked memory)");
+    if (int r = set_dev(c)) return r;
+    if (!c->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_read_ready, hipEventDisableTiming));
+        for (hipEvent_t& e : c->ev_read_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int t = c->read_issued, slot = t & 7;
+    if (t >= 8) HIP_TRY(hipEventSynchronize(c->ev_read_done[slot]));      // ticket t - 8 gives up its slot: its copy must have landed
+    HIP_TRY(hipEventRecord(c->ev_read_ready, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_read_ready, 0));
+    HIP_TRY(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->ev_read_done[slot], c->copy_stream));
+    c->read_pending[which] = t;
+    c->read_issued = t + 1;
+    *ticket = t;
+    return RTPBR_OK;
+}
+
+extern "C" int rtpbr_read_wait(rtpbr_ctx* c, int ticket) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (ticket < 0 || ticket >= c->read_issued) return fail(RTPBR_EINVAL, "rtpbr_read_wait: no such ticket");
+    if (ticket + 8 < c->read_issued) return RTPBR_OK;      // its slot was handed on, after its copy had landed
+    if (int r = set_dev(c)) return r;
+    HIP_TRY(hipEventSynchronize(c->ev_read_done[ticket & 7]));
+    return RTPBR_OK;
+}
+
 extern "C" int rtpbr_host_alloc(rtpbr_ctx* c, size_t nbytes, void** ptr) {
     if (!c || !ptr || nbytes == 0) return fail(RTPBR_EINVAL, "rtpbr_host_alloc: context, size and result pointer are required");
     if (int r = set_dev(c)) return r;
     void* p = nullptr;
     HIP_TRY(hipHostMalloc(&p, nbytes, hipHostMallocDefault));
     c->host_blocks.push_back(p);
+    c->host_sizes.push_back(nbytes);
     *ptr = p;
     return RTPBR_OK;
 }
@@ -1009,7 +1089,9 @@ extern "C" int rtpbr_host_free(rtpbr_ctx* c, void* ptr) {
         if (c->host_blocks[i] == ptr) {
             if (int r = set_dev(c)) return r;
             HIP_TRY(hipStreamSynchronize(c->stream));      // (a copy into it may be in flight)
+            if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
             c->host_blocks.erase(c->host_blocks.begin() + (long)i);
+            c->host_sizes.erase(c->host_sizes.begin() + (long)i);
             HIP_TRY(hipHostFree(ptr));
             return RTPBR_OK;
         }
@@ -1022,6 +1104,7 @@ extern "C" int rtpbr_write_buffer(rtpbr_ctx* c, int which, const void* src, size
     if (int r = buf_ptr(c, which, &p, &n)) return r;
     if (!src || nbytes != n) return fail(RTPBR_EINVAL, "source size does not match the buffer");
     if (int r = set_dev(c)) return r;
+    if (int r = rt_order_after_reads(c, 1u << which)) return r;
     HIP_TRY(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTPBR_OK;
@@ -1047,6 +1130,7 @@ extern "C" int rtpbr_unpack_tiles(rtpbr_ctx* c, const void* device_src, int src_
     if (!c || !device_src || !c->have_cfg) return fail(RTPBR_EINVAL, "bad unpack_tiles arguments");
     if (src_rank < 0 || src_rank >= c->world) return fail(RTPBR_EINVAL, "src_rank out of range");
     if (int r = set_dev(c)) return r;
+    if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER)) return r;
     Params P = c->P;
     P.cfg = c->cfg;
     P.image_buffer = c->image_buffer;
@@ -1224,6 +1308,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "src_track")) {
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "src_track must be 0 (never), 1 (one-object bounds only) or 2 (one- and two-object bounds)");
         c->src_track = (int)value;
+    } else if (!strcmp(key, "src_op")) {
+        if (value < 0 || value > 3) return fail(RTPBR_EINVAL, "src_op must be 0 (never) .. 3 (bit 0: object-parallel evaluation for sparse waves in the split march and chain kernels, bit 1: in the fused pool kernel)");
+        c->src_op = (int)value;
     } else if (!strcmp(key, "age_weights")) {
         // one hex digit per residency slot, oldest first (0x88888 = equal shares); 0 switches the weighting off
         if (value < 0 || value > 0xffffffffLL) return fail(RTPBR_EINVAL, "age_weights must be 0 (off) or up to 8 hex digits, one per residency slot");

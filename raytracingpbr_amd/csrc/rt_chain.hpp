@@ -22,7 +22,9 @@ namespace rt {
 template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
 RT_D void chain_steps_impl(const Params& P, int steps) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
+    __shared__ float4 xch_all[4][8];      // per wave: the exchange buffer of the object-parallel evaluation (nearest_op3)
     stage_objects(P, lds_obj);
+    const OpView OV = {lds_obj, ((P.src_op & 1) != 0 && P.n_obj <= 8) ? xch_all[threadIdx.x >> 6] : nullptr};
     const int lane = threadIdx.x & 63;
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     uint32_t n_steps = 0, n_raycasts = 0, n_hits = 0, n_sky = 0, n_samples = 0, n_dep = 0;
@@ -65,7 +67,7 @@ RT_D void chain_steps_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
         const unsigned long long t_w0 = __builtin_readcyclecounter();
         unsigned long long t_march = 0;
-        unsigned dbg_form[5] = {0, 0, 0, 0, 0}, dbg_steps[5] = {0, 0, 0, 0, 0};
+        unsigned dbg_form[6] = {0, 0, 0, 0, 0, 0}, dbg_steps[6] = {0, 0, 0, 0, 0, 0};
 #endif
         for (int s = 0; s < steps; s++) {
             uint32_t key = 0, cnt = 0;
@@ -116,11 +118,11 @@ RT_D void chain_steps_impl(const Params& P, int steps) {
                     if (trk_ok) {
                         int it = 1;
 #ifdef RT_DEBUG_PHASE
-                        const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it, nullptr, nullptr, OV);
                         dbg_form[form]++;
                         dbg_steps[form] += (unsigned)it;
 #else
-                        tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
+                        tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it, nullptr, nullptr, OV);
 #endif
                     } else if (L.state == ST_MARCH) {
                         march_step_src<KIND, NOBJ, SIG>(P, L);

@@ -136,12 +136,20 @@ struct rtpbr_ctx {
     int tiny_own = 8;             // pixels per small heavy wave (2 or 4 when the budget allows)
     int leave_x8 = 24;            // a shading pass costs the marching lanes about 3 march iterations
     int src_track = 2;            // tracked-object march steps (heavy waves, sparse phases): 0 off, 1 one-object bounds, 2 also the two-object lean loop
+    int src_op = 3;               // object-parallel nearest() while at most 8 lanes march: bit 0 split march + chain kernel, bit 1 fused pool kernel
     int heavy_prio = 1;           // heavy waves run at raised issue priority
     int heavy_mean_x16 = 48;      // a pixel is heavy when its cost exceeds 3 x the mean pixel ...
     int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)
     uint32_t* cost_buffer = nullptr;   // np x u32
     unsigned int* team_counter = nullptr;   // 1024 counters x 64 bytes (split march kernel)
     std::vector<void*> host_blocks;         // page-locked host memory handed out by rtpbr_host_alloc (freed with the context)
+    std::vector<size_t> host_sizes;         // ... their sizes (rtpbr_read_buffer_async checks its destination against them)
+    // asynchronous read-back (rtpbr_read_buffer_async): a copy stream, a ring of tickets, and per buffer the copy that still reads it
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_read_ready = nullptr;     // "everything enqueued so far" on the context's stream, as the copy stream sees it
+    hipEvent_t ev_read_done[8] = {};        // ticket t -> slot t % 8
+    int read_issued = 0;                    // tickets handed out so far (the next ticket)
+    int read_pending[5] = {-1, -1, -1, -1, -1};   // per RTPBR_BUF_*: the newest ticket whose copy reads it (-1: none that a writer would have to wait for)
     uint32_t* march_out = nullptr;     // np x u32 (wavefront split, rt_split.hpp); sized with cost_buffer
     size_t march_np = 0;
     int src_chain = 1;            // src/ form, fused launches: the plan's chain set runs in the chain kernel beside the pool kernel (rt_chain.hpp)
@@ -187,6 +195,7 @@ struct rtpbr_ctx {
     size_t gather_cap = 0;        // bytes of gather_send
     size_t gather_recv_cap = 0;   // bytes of gather_recv (rank 0: local share x world)
 };
+int rt_order_after_reads(rtpbr_ctx* c, unsigned mask);      // rt_capi.hip: writers of the buffers in `mask` wait (on the device) for asynchronous read-backs of them
 void rt_rccl_release(rtpbr_ctx* c);
 int rt_rccl_check_async(rtpbr_ctx* c);      // RTPBR_OK when the context has no communicator
 

@@ -278,27 +278,33 @@ template <int KIND>
 RT_D float sdf_local(const Params& P, int type, vec3 l, float sx, float sy, float sz) {
     if (KIND == KIND_BOXES) return sd_box(l, sx, sy, sz, P.cfg.box_round);
     if (KIND == KIND_BUNNY) return sd_bunny(P.bunny, l);
+    // (a run-time instance knows which shapes its scene holds: a switch on a per-lane type keeps only those cases)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_SHAPE_CASE(T) case T: if (!jit_has_type(T)) __builtin_unreachable();
+#else
+#define RT_SHAPE_CASE(T) case T:
+#endif
     switch (type) {
-        case RTPBR_SHAPE_SPHERE:
+        RT_SHAPE_CASE(RTPBR_SHAPE_SPHERE)
 #if RT_FAST_MATH && !defined(RT_FAST_EXACT_SQRT)
             return (sx > RT_BIG_EXTENT ? sqrt_big_sphere_(dot(l, l), sx) : sqrt_shape_(dot(l, l), false)) - sx;
 #else
             return sqrt_add_(dot(l, l), -sx);
 #endif
-        case RTPBR_SHAPE_BOX:
+        RT_SHAPE_CASE(RTPBR_SHAPE_BOX)
             return sd_box(l, sx, sy, sz, P.cfg.box_round);
-        case RTPBR_SHAPE_CYLINDER: {
+        RT_SHAPE_CASE(RTPBR_SHAPE_CYLINDER) {
             const bool big = sx > RT_BIG_EXTENT || sy > RT_BIG_EXTENT;
             // (|r| - sx with r a root: r >= +0, the abs is the identity; both roots take their addend in the root's own fma)
             float dx = sqrt_shape_add_(fma_(l.z, l.z, l.x * l.x), big, -sx), dy = fabs_(l.y) - sy;
             float mx = fmax_(dx, 0.0f), my = fmax_(dy, 0.0f);
             return sqrt_shape_add_(fma_(my, my, mx * mx), big, fmin_(fmax_(dx, dy), 0.0f));
         }
-        case RTPBR_SHAPE_CONE: {
+        RT_SHAPE_CASE(RTPBR_SHAPE_CONE) {
             float q = sqrt_shape_(fma_(l.z, l.z, l.x * l.x), sy > RT_BIG_EXTENT);
             return fmax_(fma_(sz, l.y, sx * q), -sy - l.y);
         }
-        case RTPBR_SHAPE_PLANE:
+        RT_SHAPE_CASE(RTPBR_SHAPE_PLANE)
             return l.y - sy;
         case RTPBR_SHAPE_BUNNY:
             if (KIND == KIND_MIXED) return sd_bunny(P.bunny, l);

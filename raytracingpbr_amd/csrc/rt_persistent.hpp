@@ -255,7 +255,10 @@ RT_D float track_eps(const Params& P, vec3 o) {
 // the allowance of a whole lean loop entered at o with the bound lb (see march_fast_src_obj): every position of the loop lies
 // within lb of o, |p|_1 within 2 lb of |o|_1
 RT_D float track_eps_loop(const Params& P, vec3 o, float lb) {
-    return 1.9073486328125e-06f * ((((fabs_(o.x) + fabs_(o.y)) + fabs_(o.z)) + P.cull_extent) + 2.0f * fmax_(lb, 0.0f));
+    // (a scene of one or two objects has second / third = 3e38: every position a distance is EVALUATED at has t < MAX_DIS — the
+    // raycast ends there — so the path marched in the loop is below min(lb, MAX_DIS); without the clamp 2 lb overflowed, the
+    // allowance was +inf and no lean loop ever took a step in such scenes: exact, but slow)
+    return 1.9073486328125e-06f * ((((fabs_(o.x) + fabs_(o.y)) + fabs_(o.z)) + P.cull_extent) + 2.0f * fmin_(fmax_(lb, 0.0f), P.cfg.max_dis));
 }
 // after a step of length s: the next position is |s| |d| away (|d| <= 1 + 2^-20); a quarter of eps covers the rounding
 // of the three coordinates (<= ulp(|p|) = eps / 16) and of the two roundings in this update (<= eps / 32 each)
@@ -266,6 +269,9 @@ RT_D float track_decay(float lb, float s_new, float eps) { return fma_(fabs_(s_n
 // keeps lb2 valid for hundreds of steps; a ray in the WEDGE between two surfaces (a sphere resting on the ground) has
 // second ~ nearest, so lb2 fails at once — measured on the launch-critical raycasts: every lean attempt failed on its first
 // step and each step cost a full evaluation plus a wasted attempt — while lb3 holds: the two-object loop below.
+#ifndef RT_POOL_OP
+#define RT_POOL_OP 0       // 1: the fused pool kernel's sparse phases use the object-parallel evaluation (nearest_op3 below) too
+#endif
 #ifndef RT_POOL_TWO
 #define RT_POOL_TWO 0      // 1: the fused pool kernel keeps both bounds too (experiment / small-frame instance)
 #endif
@@ -295,6 +301,102 @@ RT_D void march_step_src_full3(const Params& P, Lane& L, Trk& T) {
     T.lb3 = idx2 >= 0 ? track_decay(third - eps, s_new, eps) : -1.0f;
     T.k2 = idx2 >= 0 ? idx2 : idx;
 }
+// ---- OBJECT-PARALLEL nearest() for sparse waves (round 6).  A wave whose list has run out, a chain wave of a few pixels, a
+// pool wave in its drain: a handful of UNRELATED rays march, each tracking its own object, and every iteration is a full
+// evaluation (~230-330 instructions: the unrolled object loop with three-smallest tracking) executed for six lanes of 64, at a
+// lone wave's dependent-chain pace.  With at most 8 rays marching and at most 8 objects the wave evaluates them the other way
+// round: lane (r, j) = 8 r + j evaluates object j — ONE object, from the LDS table (the general-matrix form of to_local, the
+// run-time shape switch: the arithmetic of the generic ahead-of-time instance, which the run-time instances' sparse rotations
+// and literals equal bit for bit, rt_device.hpp to_local) — for the r-th marching ray, whose position it gets through an
+// 8-entry exchange buffer in LDS; a three-step DPP butterfly inside each group of eight lanes (quad_perm, quad_perm,
+// row_half_mirror: no LDS, no permute unit) yields the smallest distance, the LOWEST index that attains it (nearest() visits
+// the objects in index order with a strict `<`: src/scene.py:48-54), and — the same again with the winner masked out — the
+// second and third smallest with the second's index: everything nearest_exact3 returns.  The group's first lane writes the four
+// words back to the exchange buffer, the ray's home lane reads them.  ~140 instructions whatever the scene's shapes are
+// (the shape switch serialises the types present: sphere + box + cylinder ~ 80), independent of the number of marching rays.
+// Bit-identical by construction: the same |sdf_j|(p) per object, the same winner, valid bounds.
+struct OpView {
+    const ObjFull* lds_obj;     // the block's object table (stage_objects)
+    float4* xch;                // 8 entries of this wave: ray positions in, results out
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+RT_D uint32_t dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+#else
+template <int CTRL>
+RT_D uint32_t dpp_u32(uint32_t v) { return v; }
+#endif
+// minimum over the 8 lanes of a group (all lanes of the wave active): xor 1, xor 2 inside the quad, then the other quad of the
+// half row.  On UNSIGNED words: a distance is |sdf| >= +0, and non-negative floats order like their bit patterns (a NaN above
+// every number: it never wins, as in the serial search's `d < best`) — v_min_u32 takes the DPP operand directly, v_min_f32 would
+// be preceded by two canonicalising v_max_f32 per step.
+RT_D uint32_t seg8_min(uint32_t v) {
+    uint32_t o = dpp_u32<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = o < v ? o : v;
+    o = dpp_u32<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v = o < v ? o : v;
+    o = dpp_u32<0x141>(v);                // row_half_mirror: lane i <-> 7 - i of the eight
+    v = o < v ? o : v;
+    return v;
+}
+// Called by ALL lanes of the wave from wave-uniform control flow; at most 8 lanes `marching`, P.n_obj <= 8.  Marching lanes get
+// what nearest() returns for their position p (idx, best) and what nearest_exact3 adds: the second and third smallest distance
+// (3e38: there is none) and an object that attains the second (-1: none); `none` = nearest_init and no object within MAX_DIS
+// (nearest() then returns (0, MAX_DIS); the bounds are not to be used).
+template <int KIND>
+RT_D void nearest_op3(const Params& P, const OpView& V, bool marching, unsigned long long mm, vec3 p, int& idx, float& best, int& idx2,
+                      float& second, float& third, bool& none) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int seg = lane >> 3, j = lane & 7;
+    const int r = wave_rank(mm);
+    if (marching) V.xch[r] = make_float4(p.x, p.y, p.z, 0.0f);
+    lds_wave_fence();
+    // (groups beyond the marching rays compute on whatever the buffer holds: nobody fetches their result)
+    const float4 q = V.xch[seg];
+    const bool real = j < P.n_obj;
+    const ObjM ob = *reinterpret_cast<const ObjM*>(V.lds_obj + (real ? j : 0));
+    constexpr uint32_t BIG = 0x7f61b1e6u;      // 3.0e38f
+    const uint32_t d = real ? __builtin_bit_cast(uint32_t, fabs_(signed_distance<KIND>(P, ob, mk(q.x, q.y, q.z)))) : BIG;
+    const uint32_t m1 = seg8_min(d);
+    const uint32_t i1 = seg8_min(d == m1 ? (uint32_t)j : 8u) & 7u;      // (8 = every distance is a NaN: object 0, as the serial search)
+    const uint32_t d2 = (uint32_t)j == i1 ? BIG : d;
+    const uint32_t m2 = seg8_min(d2);
+    const uint32_t i2 = seg8_min(d2 == m2 ? (uint32_t)j : 8u) & 7u;
+    const uint32_t d3 = (((uint32_t)j == i2) & (m2 < BIG)) ? BIG : d2;
+    const uint32_t m3 = seg8_min(d3);
+    lds_wave_fence();      // every group has read its position: the buffer now takes the results
+    if (j == 0) V.xch[seg] = make_float4(__builtin_bit_cast(float, m1), __builtin_bit_cast(float, m2), __builtin_bit_cast(float, m3), __builtin_bit_cast(float, i1 | (i2 << 8)));
+    lds_wave_fence();
+    if (marching) {
+        const float4 res = V.xch[r];
+        const uint32_t ii = __builtin_bit_cast(uint32_t, res.w);
+        none = P.cfg.nearest_init && !(res.x < P.cfg.max_dis);
+        best = none ? P.cfg.max_dis : res.x;
+        idx = none ? 0 : (int)(ii & 255u);
+        second = res.y;
+        third = res.z;
+        idx2 = res.y < 3.0e38f ? (int)(ii >> 8) : -1;
+    }
+}
+// one step of raycast() for the wave's (<= 8) marching lanes on the object-parallel evaluation, both bounds fresh (what
+// march_step_src_full3 does on the unrolled one); all lanes call it
+template <int KIND>
+RT_D void march_step_src_op(const Params& P, const OpView& V, Lane& L, Trk& T) {
+    const bool marching = L.state == ST_MARCH;
+    const unsigned long long mm = __ballot(marching);
+    const float eps = track_eps(P, L.o);
+    int idx = 0, idx2 = -1;
+    float dist = 0.0f, second = 3.0e38f, third = 3.0e38f;
+    bool none = false;
+    nearest_op3<KIND>(P, V, marching, mm, L.o, idx, dist, idx2, second, third, none);
+    if (marching) {
+        const float s_new = march_update_src(P, L, idx, dist);
+        T.lb2 = none ? -1.0f : track_decay(second - eps, s_new, eps);
+        T.lb3 = ((idx2 >= 0) & !none) ? track_decay(third - eps, s_new, eps) : -1.0f;
+        T.k2 = idx2 >= 0 ? idx2 : idx;
+    }
+}
+
 // `can`: marching lanes whose lb is valid.  Lanes track different objects: one round per distinct object (grazing rays
 // share theirs), each a wave-uniform jump into that object's unrolled code.
 template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
@@ -464,7 +566,9 @@ RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max
 //   1  every lane's lb2 promises to hold and all track the same object: the one-object lean loop (until a lane stops);
 //   2  every lane's lb3 promises to hold and all track the same pair: the two-object lean loop;
 //   3  lanes with a valid lb2 take one tracked step each on their own object — unless too many would have to wait;
-//   4  a full evaluation for everybody (three smallest distances: both bounds fresh).
+//   4  a full evaluation for everybody (three smallest distances: both bounds fresh);
+//   5  (callers that pass an OpView; at most 8 lanes marching, at most 8 objects, option src_op) the object-parallel evaluation
+//      in place of 3 and 4.
 // "Promises": lb > the lane's LAST distance — a predictor only (the loops test exactly); it keeps a wedge ray from paying
 // for a one-object attempt that fails on its first step after every full evaluation.  Returns the form taken; `steps` =
 // iterations of a lean loop (1 otherwise).
@@ -473,7 +577,8 @@ RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max
 // with the second bound unused, 70.3 ms used: the sparse phases of its light waves are too short to win it back); the march
 // kernel of the wavefront split (rt_split.hpp), whose launch is as long as its slowest raycast, does.
 template <int KIND, int NOBJ, uint32_t SIG, bool TWO = false>
-RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int max_it, int& steps, unsigned long long* dbg_rounds = nullptr, int* why = nullptr) {
+RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int max_it, int& steps, unsigned long long* dbg_rounds = nullptr, int* why = nullptr,
+                           const OpView V = OpView{nullptr, nullptr}) {
     const bool marching = L.state == ST_MARCH;
     const unsigned long long mm = __ballot(marching);
     const int first = (int)__builtin_ctzll(mm);
@@ -502,6 +607,12 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
             else steps = march_fast2_src<KIND, NOBJ, SIG>(P, L, T, key0 & 255, key0 >> 8, max_it);
             return 2;
         }
+    }
+    // (round 6) a handful of rays that do not share their object(s): one object-parallel evaluation serves them all, in half the
+    // instructions of the unrolled one and with both bounds fresh — form 5 replaces forms 3 and 4 while at most 8 lanes march
+    if (V.xch != nullptr && n_march <= 8) {      // (the caller passes a buffer only when option src_op asks for it and the scene has <= 8 objects)
+        march_step_src_op<KIND>(P, V, L, T);
+        return 5;
     }
     const bool can = marching && T.lb2 > 0.0f;
     const int n_can = __popcll(__ballot(can));
@@ -594,6 +705,9 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     __shared__ uint32_t pool_all[4][G_COUNT][64];
     __shared__ uint32_t sstate_all[4][64];
     __shared__ uint32_t tbl_all[4][64];
+#if RT_POOL_OP
+    __shared__ float4 xch_all[4][8];
+#endif
     stage_objects(P, lds_obj);
 
     const unsigned long long t_wave0 = __builtin_readcyclecounter();
@@ -602,6 +716,13 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
     uint32_t (*pool)[64] = pool_all[wave];
     uint32_t* sstate = sstate_all[wave];
     const PoolView V = {pool_all[wave], sstate_all[wave], tbl_all[wave]};
+    // (RT_POOL_OP: compile-time — the fused pool kernel runs at its register limit, 96 VGPRs for five waves per SIMD: with the
+    // object-parallel step compiled in it spills 10 registers instead of 2)
+#if RT_POOL_OP
+    const OpView OV = {lds_obj, ((P.src_op & 2) != 0 && P.n_obj <= 8) ? xch_all[wave] : nullptr};
+#else
+    const OpView OV = {lds_obj, nullptr};
+#endif
     sstate[lane] = SL_EMPTY;
 
     // ---- what this wave owns and how it walks it (all wave-uniform).  Heavy waves first: wave 0 of every block, then
@@ -982,14 +1103,14 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
                         int it = 1;
 #if RT_DEBUG_PHASE == 4
                         int why = 0;
-                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, &why);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, &why, OV);
                         if (form == 1) dbg4[why]++;
                         dbg4[3 + form]++;                     // [4..7]: iterations by form
                         dbg4[7 + form] += (unsigned)it;       // [8..11]: steps by form
 #elif defined(RT_DEBUG_PHASE)
-                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, &dbg_trk_rounds, nullptr, OV);
 #else
-                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it);
+                        const int form = tracked_iteration<KIND, NOBJ, SIG, (RT_POOL_TWO != 0)>(P, L, Tk, n_march, max_it, it, nullptr, nullptr, OV);
 #endif
                         if (form <= 2 && n_ready == 0) waste += n_shade0 * (it - 1);      // (the last step is accounted below)
 #ifdef RT_DEBUG_PHASE

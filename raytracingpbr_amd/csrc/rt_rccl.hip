@@ -203,6 +203,7 @@ static int enqueue_gather(rtpbr_ctx* c, bool* collective_failed) {
 static int enqueue_unpack(rtpbr_ctx* c) {
     if (c->rank != 0) return RTPBR_OK;
     RT_HIP_TRY(hipSetDevice(c->device));
+    if (int r = rt_order_after_reads(c, 1u << RTPBR_BUF_IMAGE_BUFFER)) return r;      // (an asynchronous read-back of T7 may still be copying)
     for (int src = 1; src < c->world; src++) {       // rank 0's own tiles are already in place
         Params P = c->P;
         P.cfg = c->cfg;

@@ -86,6 +86,11 @@ enum { E_Q = 0, E_PI, E_WORD, E_OX, E_OY, E_OZ, E_DX, E_DY, E_DZ,
 template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
 RT_D void src_march_impl(const Params& P) {
     __shared__ uint32_t cur_all[4][E_COUNT][64];
+    // the object table in LDS and an 8-entry exchange buffer per wave: the object-parallel evaluation of sparse waves (nearest_op3)
+    __shared__ ObjFull lds_obj[MAX_OBJ];
+    __shared__ float4 xch_all[4][8];
+    stage_objects(P, lds_obj);
+    const OpView OV = {lds_obj, ((P.src_op & 1) != 0 && P.n_obj <= 8) ? xch_all[threadIdx.x >> 6] : nullptr};
     const int lane = threadIdx.x & 63;
     uint32_t (*cur)[64] = cur_all[threadIdx.x >> 6];
     Lane L;
@@ -119,7 +124,7 @@ RT_D void src_march_impl(const Params& P) {
     const int kwait = P.wait_lanes;
 #ifdef RT_DEBUG_PHASE
     const unsigned long long t_wave0 = __builtin_readcyclecounter();
-    unsigned dbg_iters = 0, dbg_iters_seq = 0, dbg_fast_calls = 0, dbg_fast_steps = 0, dbg_fast2_calls = 0, dbg_fast2_steps = 0, dbg_full2 = 0, dbg_trk = 0, dbg_plain = 0, dbg_tail_lanesteps = 0;
+    unsigned dbg_iters = 0, dbg_iters_seq = 0, dbg_fast_calls = 0, dbg_fast_steps = 0, dbg_fast2_calls = 0, dbg_fast2_steps = 0, dbg_full2 = 0, dbg_trk = 0, dbg_plain = 0, dbg_tail_lanesteps = 0, dbg_op = 0;
     unsigned long long t_seq_done = 0;
     uint32_t a_item = 0;
     const uint32_t h = (blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -293,12 +298,13 @@ RT_D void src_march_impl(const Params& P) {
                     const uint32_t steps_before = L.n_steps;
 #endif
                     int it = 1;
-                    const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it);
+                    const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it, nullptr, nullptr, OV);
                     (void)form;
 #ifdef RT_DEBUG_PHASE
                     if (form == 1) { dbg_fast_calls++; dbg_fast_steps += (unsigned)it; }
                     else if (form == 2) { dbg_fast2_calls++; dbg_fast2_steps += (unsigned)it; }
                     else if (form == 3) dbg_trk++;
+                    else if (form == 5) dbg_op++;
                     else dbg_full2++;
                     if (t_seq_done) dbg_tail_lanesteps += wave_sum(L.n_steps - steps_before);
                     dbg_iters++;
@@ -327,7 +333,7 @@ RT_D void src_march_impl(const Params& P) {
         w[2] = __builtin_readcyclecounter();
         w[3] = (unsigned long long)dbg_iters | ((unsigned long long)dbg_iters_seq << 32);
         w[4] = (unsigned long long)dbg_fast_calls | ((unsigned long long)dbg_fast_steps << 32);
-        w[5] = (unsigned long long)dbg_full2 | ((unsigned long long)dbg_trk << 32);
+        w[5] = (unsigned long long)(dbg_full2 & 0xffffu) | ((unsigned long long)(dbg_op & 0xffffu) << 16) | ((unsigned long long)dbg_trk << 32);      // full evaluations | object-parallel ones << 16 | tracked rounds << 32
         w[6] = (unsigned long long)dbg_plain | ((unsigned long long)dbg_tail_lanesteps << 32);
         w[7] = (unsigned long long)dbg_fast2_calls | ((unsigned long long)dbg_fast2_steps << 32);
     }

@@ -58,6 +58,14 @@ constexpr int sig_offset(uint32_t sig, int i) {
 #define RT_JIT_TYPES 0ull
 #endif
 constexpr int jit_type(int i) { return i < 16 ? (int)((RT_JIT_TYPES >> (4 * i)) & 15ull) - 1 : -1; }
+// ... so a shape switch on a PER-LANE type (the object-parallel evaluation of sparse waves, rt_persistent.hpp nearest_op3) only
+// needs the cases of the shapes the scene holds
+constexpr bool jit_has_type(int t) {
+    if (RT_JIT_TYPES == 0ull) return true;
+    for (int i = 0; i < 16; i++)
+        if ((int)((RT_JIT_TYPES >> (4 * i)) & 15ull) - 1 == t) return true;
+    return false;
+}
 // ... and, with option "jit_bake", the march table itself: RT_JIT_TABLE_FILE is a generated header that defines
 //   static constexpr uint32_t RT_JIT_TABLE_BITS[RT_JIT_NOBJ][16]     (the ObjM blocks, bit patterns)
 // so that positions, matrix entries and sizes become instruction literals (no scalar loads, no SGPRs for them).
@@ -169,6 +177,8 @@ struct Params {
     int32_t leave_x8;       // src/ pool kernel: cost of leaving the march loop for a shading pass, in eighths of a march iteration of the wave
     int32_t chain_on;       // src/ pool kernel: 1 = the plan's chain set is walked by the chain kernel (rt_chain.hpp): skip it here
     int32_t src_track;      // src/ pool kernel: 1 = tracked-object march steps enabled
+    int32_t src_op;         // src/ kernels: bit 0 = object-parallel evaluation while at most 8 lanes march (rt_persistent.hpp nearest_op3) in the split march
+                            // and chain kernels, bit 1 = in the fused pool kernel as well
     int32_t heavy_prio;     // src/ pool kernel: 1 = heavy waves raise their issue priority (s_setprio)
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU

@@ -28,6 +28,7 @@ class Renderer:
         self.api.call("create", int(device), C.byref(self._ctx))
         self.device = device
         self.samples_per_frame = 1           # SAMPLES_PER_FRAME, src/config.py:9
+        self._host_arrays = {}               # address -> bytes of the page-locked blocks handed out by host_array()
         self.set_config(config)
         self.set_scene(scene)
         self.set_camera(camera if camera is not None else scene.camera)
@@ -119,13 +120,57 @@ class Renderer:
 
     def host_array(self, which):
         """A page-locked numpy array of a buffer's shape (rtpbr_host_alloc): the destination a host that shows every frame reads
-        into again and again — ``r.read_into(BUF_IMAGE_PIXELS, a)``.  Lives as long as the renderer."""
+        into again and again — ``r.read_into(BUF_IMAGE_PIXELS, a)`` or ``r.read_async(BUF_IMAGE_PIXELS, a)``.  The memory
+        belongs to the renderer (numpy cannot own page-locked memory): it is released by ``host_release(a)`` or, with every
+        other block, by ``close()`` — the array must not be touched after either.  Copy (``a.copy()``) what has to outlive them."""
         shape, dt = self._shape(which)
         n = int(np.prod(shape)) * np.dtype(dt).itemsize
         ptr = C.c_void_p()
         self.api.call("host_alloc", self._ctx, n, C.byref(ptr))
         buf = (C.c_char * n).from_address(ptr.value)
-        return np.frombuffer(buf, dtype=dt).reshape(shape)
+        a = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._host_arrays[ptr.value] = n
+        return a
+
+    def host_release(self, arr):
+        """Give a host_array() block back (rtpbr_host_free); waits for copies into it.  The array is dead afterwards."""
+        addr = arr.ctypes.data
+        if addr not in self._host_arrays:
+            raise ValueError("not an array of this renderer's host_array()")
+        self.api.call("host_free", self._ctx, C.c_void_p(addr))
+        del self._host_arrays[addr]
+
+    # ------------------------------------------------------------ the frame without a stall (round 6)
+    def device_ptr(self, which):
+        """(device address, bytes) of a buffer: zero copy for a consumer on the same GPU — what ``canvas.set_image(image_pixels)``
+        does in the reference (src/main.py:64).  Order the consumer behind ``stream()`` (or call ``sync()``)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self.api.call("buffer_device_ptr", self._ctx, which, C.byref(ptr), C.byref(n))
+        return ptr.value, n.value
+
+    def device_array(self, which):
+        """The buffer as an object with ``__cuda_array_interface__`` (no copy): ``torch.as_tensor(r.device_array(BUF_IMAGE_PIXELS),
+        device="cuda")`` is a tensor ON the renderer's memory."""
+        addr, _ = self.device_ptr(which)
+        shape, dt = self._shape(which)
+
+        class _DeviceView:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dt).str, "data": (addr, False), "version": 2, "strides": None}
+        return _DeviceView()
+
+    def read_async(self, which, out) -> int:
+        """Enqueue the copy of a buffer into a ``host_array()`` behind everything enqueued so far and return a ticket at once; the
+        renderer's next kernels run while the copy is in flight (only a call that overwrites the buffer waits for it, on the
+        device).  ``read_wait(ticket)`` blocks until ``out`` holds the frame."""
+        shape, dt = self._shape(which)
+        if out.shape != tuple(shape) or out.dtype != np.dtype(dt) or not out.flags.c_contiguous:
+            raise ValueError(f"expected a C-contiguous {dt} array of shape {shape}")
+        t = C.c_int()
+        self.api.call("read_buffer_async", self._ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes, C.byref(t))
+        return t.value
+
+    def read_wait(self, ticket: int):
+        self.api.call("read_wait", self._ctx, int(ticket))
 
     def read_into(self, which, out):
         """field.to_numpy() into an array the caller keeps (any C-contiguous array of the buffer's shape and dtype)."""
@@ -236,9 +281,12 @@ class Renderer:
         return s.value or 0
 
     def close(self):
+        """rtpbr_destroy: frees the device buffers AND every host_array() block — arrays obtained from host_array() must not be
+        used afterwards (their memory is gone)."""
         if self._ctx:
             self.api.call("destroy", self._ctx)
             self._ctx = C.c_void_p()
+            self._host_arrays.clear()
 
     def __del__(self):
         try:

@@ -37,6 +37,13 @@ def random_case(seed):
     if persistent:
         cfg = Config.src(W, H, seed, steps_per_launch=int(rng.integers(1, 4)))
         cfg.primary_miss = int(rng.integers(0, 2))
+        # self-adaptive sampling (src/config.py:14,17; src/pathtracer.py:97-101; src/postprocessor.py:40-43) on a third of the
+        # src/ scenes (its own generator: the scenes of earlier rounds keep their draws); run() then drives the launches the
+        # way the reference's render() does — post_process() after every pathtrace() call
+        arng = np.random.default_rng(7000 + seed)
+        if seed % 3 == 2 or seed % 8 == 5:
+            cfg.adaptive_sampling = 1
+            cfg.noise_threshold = float(arng.choice([0.02, 0.08, 0.3]))
     else:
         cfg = Config.scene_demo(W, H, seed, int(rng.integers(1, 12)))
         cfg.march_kind = int(rng.integers(0, 2))
@@ -67,6 +74,14 @@ def random_case(seed):
 def run(r, env, n, persistent):
     if env is not None:
         r.set_env(env, 1.8, 2.2)
+    if persistent and r.config.adaptive_sampling:
+        # ADAPTIVE_SAMPLING: refresh() initialises the statistics, every launch is followed by post_process() (src/renderer.py:25-32);
+        # launches of n, n + 1 and then single steps, so that the mask changes between launches of every size
+        r.refresh()
+        for k in (n, n + 1, 1, 1, 2, 1, 1):
+            r.sample(k)
+            r.post_process()
+        return r
     r.sample(n)
     if persistent:
         r.sample(n + 1)

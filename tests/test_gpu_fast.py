@@ -146,23 +146,34 @@ def test_subframe_at_full_sample_count_l2(name, tile, rank, world):
 
 def test_src_form_l2():
     """The src/ persistent-ray pipeline (tracked-object march, cost-ordered ownership and all) in the tolerance flavour:
-    768x432 (the reference's default window, src/config.py:7-8), 512 launches of one bounce-step per pixel."""
+    768x432 (the reference's default window, src/config.py:7-8), 512 bounce-steps per pixel — as ONE fused call (the pool and
+    chain kernels) and as the reference issues them (src/renderer.py:29-30, src/pathtracer.py:94-103): 512 launches of
+    pathtrace() with one bounce-step each, i.e. the wavefront split (src_gen / src_march / src_shade) in this flavour."""
     wl = workloads.get("src", 768, 432)
-    g = hip(wl, 1)
-    g.set_option("plan_interval", 64)
     o = OracleRenderer(wl.scene, wl.cfg)
     wl.setup(o)
-    for r in (g, o):
-        r.refresh()
-        r.sample(512)
-        r.post_process()
-    d_disp = l2(g.image_pixels, o.image_pixels)
-    n_g, n_o = g.image_buffer[..., 3], o.image_buffer[..., 3]
-    print(f"[fast] src 768x432 x 512 bounce-steps: display-space L2 {d_disp:.3e}; deposits per pixel {n_g.mean():.2f} vs {n_o.mean():.2f}, "
-          f"pixels whose deposit count differs {float(np.mean(n_g != n_o)):.2e}")
-    assert np.all(np.isfinite(g.image_pixels))
-    assert d_disp < L2_BAR
-    g.close()
+    o.refresh()
+    o.sample(512)
+    o.post_process()
+    n_o = o.image_buffer[..., 3]
+    for how in ("fused", "one step per launch"):
+        g = hip(wl, 1)
+        g.set_option("plan_interval", 64)
+        g.refresh()
+        if how == "fused":
+            g.sample(512)
+        else:
+            for _ in range(512):
+                g.sample(1)
+        g.post_process()
+        assert g.counter("jit_active") == 1
+        d_disp = l2(g.image_pixels, o.image_pixels)
+        n_g = g.image_buffer[..., 3]
+        print(f"[fast] src 768x432 x 512 bounce-steps, {how}: display-space L2 {d_disp:.3e}; deposits per pixel {n_g.mean():.2f} vs {n_o.mean():.2f}, "
+              f"pixels whose deposit count differs {float(np.mean(n_g != n_o)):.2e}")
+        assert np.all(np.isfinite(g.image_pixels))
+        assert d_disp < L2_BAR
+        g.close()
 
 
 # (the neural SDF is a fit with |grad| between 0.6 and 1.1 and its normals are finite differences over 1e-4: a sample's path

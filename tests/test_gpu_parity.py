@@ -270,7 +270,15 @@ def test_persistent_form_schedulers_agree():
                         ({"scheduler": 1, "src_split": 1, "plan_interval": 2}, (1, 1, 1, 1, 1, 1, 42)),
                         ({"scheduler": 1, "src_split": 256, "jit": 0, "chunk": 7, "split_wait": 64}, (24, 24)),
                         ({"scheduler": 1, "src_split": 256, "sparse_lanes": 64, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "plan_interval": 1}, (1, 7, 40)),
-                        ({"scheduler": 1, "src_split": 256, "jit": 1, "jit_bake": 1, "src_track": 0, "waves_per_cu": 4}, (3, 45))):
+                        ({"scheduler": 1, "src_split": 256, "jit": 1, "jit_bake": 1, "src_track": 0, "waves_per_cu": 4}, (3, 45)),
+                        # the object-parallel evaluation of sparse waves (round 6, nearest_op3: lane = (ray, object) while at most 8
+                        # lanes march) is ON in every set above that runs the split march or the chain kernel; here: off, and on in
+                        # tiny grids where nearly every iteration is sparse, ahead-of-time and run-time instances
+                        ({"scheduler": 1, "src_split": 256, "src_op": 0}, (48,)),
+                        ({"scheduler": 1, "src_split": 256, "src_op": 1, "grid_blocks": 64, "split_wait": 1, "jit": 0}, (24, 24)),
+                        ({"scheduler": 1, "src_split": 256, "src_op": 1, "sparse_lanes": 8, "jit": 1, "jit_bake": 1, "plan_interval": 4}, (5, 43)),
+                        ({"scheduler": 1, "src_chain": 2, "src_op": 0, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8}, (2, 6, 40)),
+                        ({"scheduler": 1, "src_chain": 2, "src_op": 1, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8, "jit": 1, "jit_bake": 1}, (2, 6, 40))):
         r = Renderer(case.scene, case.cfg)
         case.setup(r)
         for k, v in opts.items():
@@ -285,6 +293,54 @@ def test_persistent_form_schedulers_agree():
             ref = got
         assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2], opts
         r.close()
+
+
+def test_adaptive_sampling_through_every_src_kernel():
+    """ADAPTIVE_SAMPLING = True the way the reference drives it (src/renderer.py:25-32, src/pathtracer.py:94-103,
+    src/postprocessor.py:40-43): render() = ONE pathtrace() of ONE bounce-step + post_process(), 48 times; the mask
+    (diff_pixels > NOISE_THRESHOLD) starts to bite around launch 20 and has emptied the frame by launch 44.  Through every
+    kernel that carries the mask: the wavefront split (src_gen), the fused pool kernel, the chain kernel with every pixel in
+    the chain set, the lock-step kernel; ahead-of-time and run-time compiled instances; with and without the object-parallel
+    evaluation of sparse waves.  image_buffer, ray_buffer, diff_buffer, diff_pixels and image_pixels bit for bit the oracle's,
+    half way and at the end."""
+    from raytracingpbr_amd import src_scene
+    from cases import _env
+    cfg = Config.src(64, 36, 11, steps_per_launch=1).copy(adaptive_sampling=1, noise_threshold=0.05)
+    sc = src_scene(aspect=64 / 36)
+
+    def state(r):
+        return tuple(bits(x).copy() for x in (r.image_buffer, r.ray_buffer, r.diff_buffer, r.diff_pixels, r.image_pixels))
+
+    o = OracleRenderer(sc, cfg)
+    o.set_env(_env(), 1.4, 2.2)
+    o.refresh()
+    want, masked = {}, []
+    for i in range(48):
+        o.sample(1)
+        o.post_process()
+        masked.append(int((o.diff_pixels > cfg.noise_threshold).sum()))
+        if i in (29, 47):
+            want[i] = state(o)
+    assert masked[10] == 64 * 36 and 0 < masked[29] < 64 * 36 and masked[47] == 0      # the mask acts inside the run
+    for opts in ({}, {"src_split": 256}, {"src_split": 0}, {"src_split": 0, "src_chain": 0}, {"scheduler": 0},
+                 {"src_op": 0}, {"jit": 0}, {"jit": 0, "src_op": 0, "split_wait": 3}, {"jit": 1, "jit_bake": 1},
+                 {"jit": 1, "jit_bake": 1, "src_split": 0, "plan_interval": 2},
+                 # every pixel with a cost on record in the chain set: the chain kernel's own mask
+                 {"src_split": 0, "src_chain": 2, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8},
+                 {"src_split": 0, "src_chain": 2, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8, "jit": 1, "jit_bake": 1},
+                 {"src_split": 1, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "jit": 1}):
+        g = Renderer(sc, cfg)
+        g.set_env(_env(), 1.4, 2.2)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        g.refresh()
+        for i in range(48):
+            g.render()                                      # sample(1) + post_process(), the reference's render()
+            if i in want:
+                got = state(g)
+                for name, a, b in zip(("image_buffer", "ray_buffer", "diff_buffer", "diff_pixels", "image_pixels"), got, want[i]):
+                    assert np.array_equal(a, b), (opts, i, name)
+        g.close()
 
 
 def test_persistent_form_tile_partition():
@@ -392,6 +448,66 @@ def test_read_into_page_locked_host_buffer():
         r.api.call("host_free", r._ctx, C.cast(junk, C.c_void_p))
     r.api.call("host_free", r._ctx, C.c_void_p(pinned.ctypes.data))
     r.close()                      # (frees `acc` with the context)
+
+
+def test_frames_handed_over_without_a_stall_equal_the_synchronous_path():
+    """rtpbr_read_buffer_async / rtpbr_read_wait / rtpbr_buffer_device_ptr (round 6): the reference hands image_pixels to its
+    window on the device and goes straight on to the next render() (src/main.py:62-64).  Frame k's read-back is enqueued, frame
+    k+1 is rendered while it is in flight, and every DELIVERED frame holds the bits the blocking path gives; a read of
+    image_buffer followed at once by more samples returns the state at the time of the call (the writer waits on the device);
+    more tickets than slots; pageable destinations and unknown tickets are refused; the device pointer is the buffer."""
+    import torch
+    from raytracingpbr_amd.renderer import BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS
+    case = case_by_name("src_persistent")
+    a, b = Renderer(case.scene, case.cfg), Renderer(case.scene, case.cfg)
+    case.setup(a)
+    case.setup(b)
+    want = []
+    for k in range(20):
+        a.render()
+        want.append(bits(a.image_pixels).copy())
+    pinned = [b.host_array(BUF_IMAGE_PIXELS) for _ in range(2)]
+    prev = None
+    for k in range(20):
+        b.render()
+        t = b.read_async(BUF_IMAGE_PIXELS, pinned[k % 2])
+        if prev is not None:
+            b.read_wait(prev)
+            assert np.array_equal(bits(pinned[(k - 1) % 2]), want[k - 1]), k - 1
+        prev = t
+    b.read_wait(prev)
+    assert np.array_equal(bits(pinned[1]), want[19])
+    b.read_wait(0)                                       # a ticket whose slot has long been handed on: done by definition
+    # image_buffer: the copy sees the state at the call, although sample() is enqueued right behind it
+    acc = b.host_array(BUF_IMAGE_BUFFER)
+    snap = bits(b.image_buffer).copy()
+    t = b.read_async(BUF_IMAGE_BUFFER, acc)
+    b.sample(6)
+    b.refresh()
+    b.read_wait(t)
+    assert np.array_equal(bits(acc), snap)
+    # more outstanding tickets than the ring holds
+    ts = [b.read_async(BUF_IMAGE_PIXELS, pinned[0]) for _ in range(19)]
+    for t in ts:
+        b.read_wait(t)
+    with pytest.raises(RtpbrError):
+        b.read_async(BUF_IMAGE_PIXELS, np.empty_like(pinned[0]))          # pageable memory
+    with pytest.raises(RtpbrError):
+        b.read_wait(10 ** 6)
+    with pytest.raises(ValueError):
+        b.read_async(BUF_IMAGE_PIXELS, acc)                               # wrong shape
+    # zero copy: a torch tensor ON the renderer's image_pixels
+    b.render()
+    b.sync()
+    tens = torch.as_tensor(b.device_array(BUF_IMAGE_PIXELS), device="cuda")
+    addr, nbytes = b.device_ptr(BUF_IMAGE_PIXELS)
+    assert tens.data_ptr() == addr and nbytes == tens.numel() * 4 and tuple(tens.shape) == (case.cfg.width, case.cfg.height, 3)
+    assert np.array_equal(bits(tens.cpu().numpy()), bits(b.image_pixels))
+    b.host_release(acc)
+    with pytest.raises(ValueError):
+        b.host_release(np.zeros(4, np.float32))
+    a.close()
+    b.close()
 
 
 def test_refresh_semantics():
@@ -687,7 +803,10 @@ def test_fuzz_random_scenes_match_oracle(seed):
                      # two-object lean loops on whatever shapes the fuzzer made, every pixel with a recorded cost on the heavy head —
                      # and with the one-bound march of round 4
                      {"src_split": 256, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "jit": seed % 2, "jit_bake": 1},
-                     {"src_split": 256, "src_track": 1, "split_wait": 5, "jit": 1 - seed % 2}):
+                     {"src_split": 256, "src_track": 1, "split_wait": 5, "jit": 1 - seed % 2},
+                     # the object-parallel evaluation (round 6) off, and with every iteration eligible (tiny waves: one block)
+                     {"src_split": 256, "src_op": 0, "jit": seed % 2},
+                     {"src_split": 256, "src_op": 1, "grid_blocks": 1, "split_wait": 1, "sparse_lanes": 64, "jit": 1 - seed % 2, "jit_bake": 1}):
             g = Renderer(sc, cfg)
             for k, v in opts.items():
                 g.set_option(k, v)

@@ -38,5 +38,9 @@ top = np.argsort(-life)[:12]
 print(json.dumps({"life_kcycles_pctl": q(life), "bulk_kcycles_pctl(start..sequence_done)": q(seq - start),
                   "slowest_waves": [{"life": round(float(life[i]), 1), "bulk": round(float(seq[i] - start[i]), 1), "iters": int(it[i]), "iters_bulk": int(its[i]),
                                      "kcycles_per_bulk_iter": round(float((seq[i] - start[i]) / max(1, its[i])), 2), "kcycles_per_tail_iter": round(float((end[i] - seq[i]) / max(1, it[i] - its[i])), 2),
-                                     "fast_calls": int(db[i, 4] & 0xffffffff), "fast_steps": int(db[i, 4] >> 32), "fast2_calls": int(db[i, 7] & 0xffffffff), "fast2_steps": int(db[i, 7] >> 32), "full2": int(db[i, 5] & 0xffffffff), "tracked": int(db[i, 5] >> 32), "plain": int(db[i, 6] & 0xffffffff), "tail_lanesteps": int(db[i, 6] >> 32)} for i in top]}))
+                                     "fast_calls": int(db[i, 4] & 0xffffffff), "fast_steps": int(db[i, 4] >> 32), "fast2_calls": int(db[i, 7] & 0xffffffff), "fast2_steps": int(db[i, 7] >> 32), "full2": int(db[i, 5] & 0xffff), "op": int((db[i, 5] >> 16) & 0xffff), "tracked": int(db[i, 5] >> 32), "plain": int(db[i, 6] & 0xffffffff), "tail_lanesteps": int(db[i, 6] >> 32)} for i in top]}))
+tot = lambda a: int(a.sum())
+print(json.dumps({"all_waves": {"iterations": tot(it), "bulk_iterations": tot(its), "lean1_calls": tot(db[:, 4] & 0xffffffff), "lean1_steps": tot(db[:, 4] >> 32), "lean2_calls": tot(db[:, 7] & 0xffffffff),
+                                "lean2_steps": tot(db[:, 7] >> 32), "full": tot(db[:, 5] & 0xffff), "op": tot((db[:, 5] >> 16) & 0xffff), "tracked": tot(db[:, 5] >> 32), "plain": tot(db[:, 6] & 0xffffffff),
+                                "tail_lanesteps": tot(db[:, 6] >> 32), "tail_kcycles_mean": round(float((end - seq).mean()), 1), "bulk_kcycles_mean": round(float((seq - start).mean()), 1)}}))
 r.close()
