@@ -838,6 +838,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
                     // (small frames are all tail: two waves per SIMD — 2 / 3 / 4 at 640x360 0.230 / 0.236 / 0.240 ms per launch, 768x432
                     // 0.258 / 0.261 / 0.270, 960x540 0.287 / 0.289 / 0.292; no difference from 1024x576 on)
                     if ((long long)P.np <= 600000 && mper > 2) mper = 2;
+                    // ... and there the heavy head of the list is interleaved over the groups (rt_split.hpp: 768x432 0.2375 -> 0.224 ms
+                    // per launch; at 1080p, four waves per SIMD, 0.469 -> 0.478: kept as it was)
+                    P.split_head = c->split_head >= 0 ? c->split_head : ((long long)P.np <= 600000 ? 1 : 0);
                     if (c->waves_per_cu > 0) mper = (c->waves_per_cu + 3) / 4;
                     long long mgrid = (long long)mper * c->n_cu;
                     const long long need = ((long long)P.np + 255) / 256;
@@ -1302,6 +1305,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "src_split")) {
         if (value < 0 || value > 256) return fail(RTPBR_EINVAL, "src_split must be 0 (never) .. 256 (bounce-steps per launch up to which the wavefront split runs)");
         c->src_split = (int)value;
+    } else if (!strcmp(key, "split_head")) {
+        if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "split_head must be -1 (automatic: small frames), 0 (the heavy head fills the first groups) or 1 (interleaved: one head entry per group)");
+        c->split_head = (int)value;
     } else if (!strcmp(key, "split_wait")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "split_wait must be 1..64");
         c->split_wait = (int)value;
@@ -1309,7 +1315,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "src_track must be 0 (never), 1 (one-object bounds only) or 2 (one- and two-object bounds)");
         c->src_track = (int)value;
     } else if (!strcmp(key, "src_op")) {
-        if (value < 0 || value > 3) return fail(RTPBR_EINVAL, "src_op must be 0 (never) .. 3 (bit 0: object-parallel evaluation for sparse waves in the split march and chain kernels, bit 1: in the fused pool kernel)");
+        if (value < 0 || value > 3) return fail(RTPBR_EINVAL, "src_op must be 0 .. 3 (bit 0: object-parallel evaluation for sparse waves in the split march and chain kernels, bit 1: in the fused pool kernel)");
         c->src_op = (int)value;
     } else if (!strcmp(key, "age_weights")) {
         // one hex digit per residency slot, oldest first (0x88888 = equal shares); 0 switches the weighting off

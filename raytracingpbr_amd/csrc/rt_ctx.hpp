@@ -159,6 +159,7 @@ struct rtpbr_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int src_split = 1;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never (measured at 1080p: one step 0.51 against 0.60 ms fused; two steps 1.3 against 0.65)
     int split_wait = 24;          // ... its march kernel refills when this many lanes are free
+    int split_head = -1;          // ... the list's heavy head interleaved over the groups: -1 = for small frames (two waves per SIMD), 0 never, 1 always
     uint32_t* order = nullptr;         // np x u32
     rt::PlanBuf* plan = nullptr;
     size_t plan_np = 0;                // pixels the three buffers are sized for

@@ -269,6 +269,14 @@ RT_D float track_decay(float lb, float s_new, float eps) { return fma_(fabs_(s_n
 // keeps lb2 valid for hundreds of steps; a ray in the WEDGE between two surfaces (a sphere resting on the ground) has
 // second ~ nearest, so lb2 fails at once — measured on the launch-critical raycasts: every lean attempt failed on its first
 // step and each step cost a full evaluation plus a wasted attempt — while lb3 holds: the two-object loop below.
+// RT_TRK_W1 = 0 drops the second instance (no relaxation bookkeeping) of every lean loop of the kernels that keep both bounds.
+// (Round 6 measured whether those kernels' CODE SIZE — 47 KB for the split march, 53 KB for the chain kernel, most of it the 21 x 2
+// pair instances — costs instruction-cache misses: one generic pair / one-object loop instance with its constants from the LDS
+// table took the march kernel to 23 / 18 KB and one-step launches from 0.239 to 0.247 / 0.250 ms at 768x432, 0.467 to 0.484 /
+// 0.488 at 1080p: the code is not the problem, the few more instructions per step are.  Removed again.)
+#ifndef RT_TRK_W1
+#define RT_TRK_W1 1
+#endif
 #ifndef RT_POOL_OP
 #define RT_POOL_OP 0       // 1: the fused pool kernel's sparse phases use the object-parallel evaluation (nearest_op3 below) too
 #endif
@@ -587,12 +595,12 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
     // the raycasts that make a launch long lose their over-relaxation within a few steps (w: 1.6 -> 1 at the first overshoot) and
     // then march hundreds of steps with w == 1: the lean loops have an instance without the relaxation bookkeeping for that
     // (kernels that keep both bounds only — the chain kernel and the split march; the fused pool kernel has no room for more code)
-    const bool w1 = TWO && __ballot(marching & (L.w != 1.0f)) == 0ull;
+    const bool w1 = TWO && (RT_TRK_W1 != 0) && __ballot(marching & (L.w != 1.0f)) == 0ull;
     // (one bound only: any valid lb2 tries the lean loop, as round 4 did)
     if (__ballot(marching & (T.lb2 > (two ? L.dist : 0.0f))) == mm) {
         const int k0 = __builtin_amdgcn_readlane(L.idx, first);
         if (__ballot(marching && L.idx != k0) == 0ull) {
-            if (TWO && w1) steps = march_fast_src<KIND, NOBJ, SIG, TWO, TWO>(P, L, T, k0, max_it, why);
+            if (TWO && (RT_TRK_W1 != 0) && w1) steps = march_fast_src<KIND, NOBJ, SIG, TWO, (TWO && RT_TRK_W1 != 0)>(P, L, T, k0, max_it, why);
             else steps = march_fast_src<KIND, NOBJ, SIG, TWO>(P, L, T, k0, max_it, why);
             return 1;
         }
@@ -603,7 +611,7 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
         const int key0 = __builtin_amdgcn_readlane(key, first);
         if (__ballot(marching && key != key0) == 0ull) {
             if (marching) T.lb2 = -1.0f;      // (re-derived by the loop's first step)
-            if (w1) steps = march_fast2_src<KIND, NOBJ, SIG, true>(P, L, T, key0 & 255, key0 >> 8, max_it);
+            if ((RT_TRK_W1 != 0) && w1) steps = march_fast2_src<KIND, NOBJ, SIG, (RT_TRK_W1 != 0)>(P, L, T, key0 & 255, key0 >> 8, max_it);
             else steps = march_fast2_src<KIND, NOBJ, SIG>(P, L, T, key0 & 255, key0 >> 8, max_it);
             return 2;
         }

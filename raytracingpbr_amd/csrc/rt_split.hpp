@@ -120,12 +120,32 @@ RT_D void src_march_impl(const Params& P) {
     const uint32_t NT = (uint32_t)P.n_teams;
     const uint32_t team = blockIdx.x % NT;
     unsigned int* const tc = P.team_counter + team * 16u;                 // one counter per 64 bytes
-    const uint32_t n_groups = (P.total_items + GS - 1u) / GS;
+    // HEAD DEALING (round 6).  The plan's heavy pixels — the head of the list, n_heavy entries: rays that graze the ground sphere or
+    // sit in a wedge for hundreds of steps — used to fill the first groups completely: at 768x432 the 2 935 heaviest rays of the
+    // frame went to 92 of the 2 048 waves, 32 each, every one tracking its own object, and those waves' tails (200 iterations of
+    // tracked rounds for ~14 lanes) WERE the launch (per-wave records, tools/gpu_split_prof.py).  Now the head is INTERLEAVED: the
+    // first n_hg groups carry HS head entries each in their first lanes and GS - HS entries of the rest of the list behind them.
+    // Every wave's first claims still hold the heaviest rays there are (they start at once), but one or two per wave: in its
+    // tail a wave is left with ITS long ray, which runs the lean loops alone, instead of a crowd that cannot.  Measured (one step
+    // per launch, object-parallel evaluation on): 768x432 0.2375 -> 0.224 ms; 1080p 0.469 -> 0.478: there the bulk phase is four
+    // waves per SIMD at 3 kcycles per iteration and a long ray that rides along takes ONE step per bulk iteration, where a head
+    // wave's tracked forms took it further — so the host interleaves for the small frames only (option split_head, rt_capi.hip).
+#ifndef RT_SPLIT_HS
+#define RT_SPLIT_HS 1       // head entries per group
+#endif
+    constexpr uint32_t HS = RT_SPLIT_HS;
+    const uint32_t n_head = P.split_head ? (n_heavy < P.total_items ? n_heavy : P.total_items) : 0u;
+    const uint32_t n_hg = (n_head + HS - 1u) / HS;                       // groups that carry head entries
+    const uint32_t bulk_hg = n_hg * (GS - HS);                           // entries of the rest of the list those groups take along
+    const uint32_t rest = P.total_items - n_head > bulk_hg ? P.total_items - n_head - bulk_hg : 0u;
+    const uint32_t n_groups = n_hg + (rest + GS - 1u) / GS;
     const int kwait = P.wait_lanes;
 #ifdef RT_DEBUG_PHASE
     const unsigned long long t_wave0 = __builtin_readcyclecounter();
     unsigned dbg_iters = 0, dbg_iters_seq = 0, dbg_fast_calls = 0, dbg_fast_steps = 0, dbg_fast2_calls = 0, dbg_fast2_steps = 0, dbg_full2 = 0, dbg_trk = 0, dbg_plain = 0, dbg_tail_lanesteps = 0, dbg_op = 0;
     unsigned long long t_seq_done = 0;
+    unsigned long long t_form[6] = {0, 0, 0, 0, 0, 0};      // tail only: cycles inside the march step by form (0 = plain steps, 1..5 = tracked_iteration's forms)
+    unsigned n_form[6] = {0, 0, 0, 0, 0, 0};
     uint32_t a_item = 0;
     const uint32_t h = (blockIdx.x * 4u + (threadIdx.x >> 6));
 #endif
@@ -149,8 +169,18 @@ RT_D void src_march_impl(const Params& P) {
         pf_g = g;
         pf_q = 0xffffffffu;
         pf_word = MS_NONE;
-        const uint32_t item = g * GS + (uint32_t)lane;
-        if (g != 0xffffffffu && (uint32_t)lane < GS && item < P.total_items) {
+        // list entry of (group g, lane): head groups interleave, the others are GS consecutive entries behind them
+        uint32_t item;
+        bool have;
+        if (g < n_hg) {
+            const bool hd = (uint32_t)lane < HS;
+            item = hd ? g * HS + (uint32_t)lane : n_head + g * (GS - HS) + ((uint32_t)lane - HS);
+            have = hd ? item < n_head : item < P.total_items;
+        } else {
+            item = n_head + bulk_hg + (g - n_hg) * GS + (uint32_t)lane;
+            have = item < P.total_items;
+        }
+        if (g != 0xffffffffu && (uint32_t)lane < GS && have) {
             const uint32_t q = P.order ? P.order[item] : item;
             int px, py;
             if (pixel_of(P, q, px, py)) {          // (a padding pixel of an edge tile has no ray: src_gen left its word at "none")
@@ -193,7 +223,7 @@ RT_D void src_march_impl(const Params& P) {
             cur[E_DY][r] = __builtin_bit_cast(uint32_t, pf_c.x);
             cur[E_DZ][r] = __builtin_bit_cast(uint32_t, pf_c.y);
 #ifdef RT_DEBUG_PHASE
-            cur[E_ITEM][r] = pf_g * GS + (uint32_t)lane;
+            cur[E_ITEM][r] = pf_g * GS + (uint32_t)lane;      // (group-major position, not the list entry, since the head is interleaved)
 #endif
         }
         lds_wave_fence();
@@ -290,17 +320,21 @@ RT_D void src_march_impl(const Params& P) {
         const int cap = n_active >> 2 > 1 ? n_active >> 2 : 1;
         const int kstar = (seq_done && kwait > cap) ? cap : kwait;
         bool tracked = false;
-        if constexpr (TRK) tracked = trk_ok && ((cur_g != 0xffffffffu && cur_g * GS <= n_heavy + GS) || n_march <= P.sparse_lanes);
+        // (with the head interleaved no wave is made of heavy rays: the tracked forms are for sparse phases; split_head = 0 is the
+        // round-5 dealing — head entries fill the first groups, whose waves track from the start)
+        if constexpr (TRK) tracked = trk_ok && ((!P.split_head && cur_g != 0xffffffffu && cur_g * GS <= n_heavy + GS) || n_march <= P.sparse_lanes);
         if (tracked) {
             if constexpr (TRK) {
                 do {
 #ifdef RT_DEBUG_PHASE
                     const uint32_t steps_before = L.n_steps;
+                    const unsigned long long t_f0 = __builtin_readcyclecounter();
 #endif
                     int it = 1;
                     const int form = tracked_iteration<KIND, NOBJ, SIG, true>(P, L, Tk, n_march, 0, it, nullptr, nullptr, OV);
                     (void)form;
 #ifdef RT_DEBUG_PHASE
+                    if (t_seq_done) { t_form[form] += __builtin_readcyclecounter() - t_f0; n_form[form]++; }
                     if (form == 1) { dbg_fast_calls++; dbg_fast_steps += (unsigned)it; }
                     else if (form == 2) { dbg_fast2_calls++; dbg_fast2_steps += (unsigned)it; }
                     else if (form == 3) dbg_trk++;
@@ -314,8 +348,12 @@ RT_D void src_march_impl(const Params& P) {
             }
         } else {
             do {
+#ifdef RT_DEBUG_PHASE
+                const unsigned long long t_f0 = __builtin_readcyclecounter();
+#endif
                 if (L.state == ST_MARCH) march_step_src<KIND, NOBJ, SIG>(P, L);
 #ifdef RT_DEBUG_PHASE
+                if (t_seq_done) { t_form[0] += __builtin_readcyclecounter() - t_f0; n_form[0]++; }
                 dbg_iters++;
                 dbg_plain++;
                 if (t_seq_done) dbg_tail_lanesteps += (unsigned)n_march;
@@ -327,7 +365,8 @@ RT_D void src_march_impl(const Params& P) {
     }
 #ifdef RT_DEBUG_PHASE
     if (lane == 0) {   // per-wave timeline, written over diff_buffer (unused without adaptive sampling; the host reads it back)
-        unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 8u;
+        unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 16u;
+        for (int f = 0; f < 6; f++) w[8 + f] = t_form[f] | ((unsigned long long)n_form[f] << 40);      // tail: cycles | calls << 40, by form
         w[0] = t_wave0;
         w[1] = t_seq_done;
         w[2] = __builtin_readcyclecounter();

@@ -179,6 +179,7 @@ struct Params {
     int32_t src_track;      // src/ pool kernel: 1 = tracked-object march steps enabled
     int32_t src_op;         // src/ kernels: bit 0 = object-parallel evaluation while at most 8 lanes march (rt_persistent.hpp nearest_op3) in the split march
                             // and chain kernels, bit 1 = in the fused pool kernel as well
+    int32_t split_head;     // split march kernel: 1 = the list's heavy head is interleaved over the groups (one entry per group), 0 = it fills the first groups
     int32_t heavy_prio;     // src/ pool kernel: 1 = heavy waves raise their issue priority (s_setprio)
     int32_t scheduler;      // 0 = in-register refill, 1 = per-wave LDS ray pool
     int32_t mlp_mfma;       // bunny: 1 = hidden layers on the matrix cores (f32 MFMA, bit-identical), 0 = VALU

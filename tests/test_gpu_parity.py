@@ -274,8 +274,8 @@ def test_persistent_form_schedulers_agree():
                         # the object-parallel evaluation of sparse waves (round 6, nearest_op3: lane = (ray, object) while at most 8
                         # lanes march) is ON in every set above that runs the split march or the chain kernel; here: off, and on in
                         # tiny grids where nearly every iteration is sparse, ahead-of-time and run-time instances
-                        ({"scheduler": 1, "src_split": 256, "src_op": 0}, (48,)),
-                        ({"scheduler": 1, "src_split": 256, "src_op": 1, "grid_blocks": 64, "split_wait": 1, "jit": 0}, (24, 24)),
+                        ({"scheduler": 1, "src_split": 256, "src_op": 0, "split_head": 0, "plan_interval": 4}, (6, 42)),
+                        ({"scheduler": 1, "src_split": 256, "src_op": 1, "grid_blocks": 64, "split_wait": 1, "jit": 0, "split_head": 1}, (24, 24)),
                         ({"scheduler": 1, "src_split": 256, "src_op": 1, "sparse_lanes": 8, "jit": 1, "jit_bake": 1, "plan_interval": 4}, (5, 43)),
                         ({"scheduler": 1, "src_chain": 2, "src_op": 0, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8}, (2, 6, 40)),
                         ({"scheduler": 1, "src_chain": 2, "src_op": 1, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "grid_blocks": 8, "jit": 1, "jit_bake": 1}, (2, 6, 40))):

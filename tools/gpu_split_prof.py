@@ -24,7 +24,7 @@ for i in range(4):
                       "longest_wave_kcycles": d[15] >> 10, "iterations_of_busiest_wave": d[7], "plan_heavy": r.counter("plan_heavy"),
                       "raycasts>128_by_list_position(<1k,2k,4k,..)": [x & 0xffffffff for x in d[16:32]], "raycasts>256_by_list_position": [x >> 32 for x in d[16:32]]}), flush=True)
 import numpy as np
-db = np.ascontiguousarray(r.diff_buffer).view(np.uint64).reshape(-1)[:8192 * 8].reshape(-1, 8)
+db = np.ascontiguousarray(r.diff_buffer).view(np.uint64).reshape(-1)[:8192 * 16].reshape(-1, 16)
 db = db[db[:, 0] > 0]
 t0 = db[:, 0].min()
 seq = (db[:, 1] - t0) / 1e3; end = (db[:, 2] - t0) / 1e3; start = (db[:, 0] - t0) / 1e3
@@ -43,4 +43,8 @@ tot = lambda a: int(a.sum())
 print(json.dumps({"all_waves": {"iterations": tot(it), "bulk_iterations": tot(its), "lean1_calls": tot(db[:, 4] & 0xffffffff), "lean1_steps": tot(db[:, 4] >> 32), "lean2_calls": tot(db[:, 7] & 0xffffffff),
                                 "lean2_steps": tot(db[:, 7] >> 32), "full": tot(db[:, 5] & 0xffff), "op": tot((db[:, 5] >> 16) & 0xffff), "tracked": tot(db[:, 5] >> 32), "plain": tot(db[:, 6] & 0xffffffff),
                                 "tail_lanesteps": tot(db[:, 6] >> 32), "tail_kcycles_mean": round(float((end - seq).mean()), 1), "bulk_kcycles_mean": round(float((seq - start).mean()), 1)}}))
+fc = db[:, 8:14] & ((1 << 40) - 1); fn = db[:, 8:14] >> 40
+print(json.dumps({"tail_by_form(plain,lean1,lean2,tracked,full,op)": {"calls": [int(x) for x in fn.sum(axis=0)], "Mcycles": [round(float(x) / 1e6, 2) for x in fc.sum(axis=0)],
+                                                                      "kcycles_per_call": [round(float(c) / max(1, int(n)) / 1e3, 3) for c, n in zip(fc.sum(axis=0), fn.sum(axis=0))]},
+                  "tail_Mcycles_total": round(float((end - seq).sum()) / 1e3, 2)}))
 r.close()
