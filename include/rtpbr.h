@@ -373,6 +373,12 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * coherent kernel for roulette / deposit / camera ray, one for the raycasts on the cost-ordered pixel list, one for shading —
  * instead of the fused pool kernel; 0 = never, default 1), "split_wait" (its march kernel refills lanes when this many are
  * free, default 24),
+ * "src_op" (round 6: bit 0 = while at most 8 lanes of a wave march — the tail of a one-step launch, a chain wave of a few pixels —
+ * the wave evaluates nearest() OBJECT-PARALLEL: lane (r, j) evaluates object j for the r-th marching ray from the LDS table and a DPP
+ * butterfly over each group of eight lanes returns nearest / second / third, bit-identical; split march and chain kernels; bit 1 =
+ * the fused pool kernel too, only in builds with -DRT_POOL_OP=1: it spills there; default 3), "split_head" (split march kernel: the
+ * cost-ordered list's heavy head interleaved over the groups, one entry per group, instead of filling the first groups: -1 = for
+ * frames of at most 600 000 pixels (default), 0 never, 1 always),
  * "src_track" (same kernel: 1 = tracked-object march steps — a lane that knows a lower bound of every object but the
  * nearest one evaluates only that one, exactly; heavy waves always use them), "sparse_lanes" (... other waves while at
  * most this many lanes march, 0 = never; default 24), "leave_x8" (cost of a shading pass in eighths of a march iteration:
@@ -407,6 +413,18 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * first use), "sample_base" (absolute index of the next sample: checkpoint/resume).
  * Returns RTPBR_EINVAL for unknown keys or out-of-range values. */
 int rtpbr_set_option(rtpbr_ctx* ctx, const char* key, long long value);
+
+/* Ahead-of-time compilation of the scene-specialised kernels (round 6) — NO DEVICE NEEDED.  Taichi compiles the reference's
+ * kernels at first call on the machine that runs them (ti.init, src/config.py:5; ti.static unrolling, src/scene.py:44-56);
+ * option "jit" does the same here and needs hipcc + the kernel sources on the target.  rtpbr_jit_prebuild compiles, on a BUILD
+ * machine, exactly the code object rtpbr_sample() would ask for with this scene (objects, scale10), configuration, camera, tile
+ * partition (tile_w, tile_h, world; rank does not matter) and options ("key=value key=value ...", as rtpbr_set_option:
+ * jit, jit_bake, precision, mlp_mfma, ...) into $RTPBR_JIT_CACHE and returns its path.  Code objects placed in the catalog
+ * directory next to the library (raytracingpbr_amd/data/jit, or $RTPBR_JIT_CATALOG) are found by rtpbr_sample() BEFORE it
+ * forks a compiler: a target without hipcc runs the baked kernels of the scenes it ships with.  `python -m
+ * raytracingpbr_amd.prebuild` fills the catalog for the BASELINE scenes (called by the package's build step). */
+int rtpbr_jit_prebuild(const rtpbr_object* objects, int n, int scale10, const rtpbr_config* cfg, const rtpbr_camera* cam,
+                       int tile_w, int tile_h, int world, const char* options, char* path_out, size_t path_cap);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ ENTRY_POINTS = [
     "read_buffer", "write_buffer", "host_alloc", "host_free", "buffer_device_ptr", "read_buffer_async", "read_wait",
     "packed_bytes", "pack_tiles", "unpack_tiles",
     "get_counters", "get_counter", "last_sample_ms", "last_primary_ms", "get_stream", "set_option", "set_shape_data",
-    "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info",
+    "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info", "jit_prebuild",
 ]
 
 
@@ -36,7 +36,7 @@ class RtpbrError(RuntimeError):
 
 
 class CApi:
-    def __init__(self, path, prefix="rtpbr_", optional=("test_math", "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info")):
+    def __init__(self, path, prefix="rtpbr_", optional=("test_math", "jit_prebuild", "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info")):
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} not found — build it first (python -c 'import __graft_entry__ as g; g.build()')")
@@ -81,6 +81,8 @@ class CApi:
             "gather_tiles": (C.c_int, [p]),
             "gather_tiles_all": (C.c_int, [C.POINTER(p), C.c_int]),
             "rccl_info": (C.c_int, [p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "jit_prebuild": (C.c_int, [C.POINTER(SDFObject), C.c_int, C.c_int, C.POINTER(Config), C.POINTER(Camera), C.c_int, C.c_int, C.c_int,
+                                       C.c_char_p, C.c_char_p, C.c_size_t]),
             "test_math": (C.c_int, [p, C.c_int, p, p, p, p, C.c_int]),
         }
         self.fn = {}

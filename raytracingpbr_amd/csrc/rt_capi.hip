@@ -10,11 +10,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "rt_ctx.hpp"
 
 using namespace rt;
+
+static void derive_launch(rtpbr_ctx* c, RtJitKey* key, bool* want, bool* strict_error);
+extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value);
+extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world);
+extern "C" int rtpbr_set_camera(rtpbr_ctx* c, const rtpbr_camera* cam);
 
 static thread_local char g_err[512];
 int rt_fail(int code, const char* fmt, const char* a) {
@@ -29,6 +35,7 @@ static int fail(int code, const char* fmt, const char* a = "") { return rt_fail(
 #define HIP_TRY(expr) RT_HIP_TRY(expr)
 
 static int set_dev(rtpbr_ctx* c) {
+    if (c->headless) return RTPBR_OK;       // (a context without a device: rtpbr_jit_prebuild derives launch constants on the host only)
     HIP_TRY(hipSetDevice(c->device));
     return RTPBR_OK;
 }
@@ -161,7 +168,7 @@ extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
     if (cfg->max_raymarch <= 0 || cfg->max_raytrace <= 0) return fail(RTPBR_EINVAL, "max_raymarch/max_raytrace must be > 0");
     if (int r = check_local_pixels(cfg->width, cfg->height, c->tile_w, c->tile_h, c->world)) return r;
     if (int r = set_dev(c)) return r;
-    bool realloc_buf = !c->have_cfg || c->cfg.width != cfg->width || c->cfg.height != cfg->height;
+    bool realloc_buf = (!c->have_cfg || c->cfg.width != cfg->width || c->cfg.height != cfg->height) && !c->headless;
     c->cfg = *cfg;
     c->P.cfg = *cfg;
     c->have_cfg = true;
@@ -317,8 +324,10 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
     c->n_obj = n;
     c->P.n_obj = n;
     c->kind = all_box ? KIND_BOXES : (all_bunny && n == 1) ? KIND_BUNNY : any_bunny ? KIND_MIXED : KIND_GENERIC;
-    HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
+    if (!c->headless) {
+        HIP_TRY(hipMemcpyAsync(c->objfull, full, sizeof(ObjFull) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // `full` is a stack buffer
+    }
     c->have_scene = true;
     return RTPBR_OK;
 }
@@ -439,6 +448,47 @@ extern "C" int rtpbr_test_jit_build_baked(const rtpbr_object* objs, int n, int s
     return RTPBR_OK;
 }
 
+// Ahead-of-time compilation of the run-time instance of ONE scene + configuration (+ camera, tiles, options) — NO DEVICE NEEDED:
+// a headless context takes the same set_config / set_scene / set_camera / set_tiles / set_option calls a rendering host makes,
+// derive_launch() forms the key rtpbr_sample() would ask for, and rt_jit_build() compiles it into $RTPBR_JIT_CACHE (or finds it
+// there / in the catalog shipped next to the library, raytracingpbr_amd/data/jit).  __graft_entry__.build() fills that catalog for the
+// BASELINE scenes this way, so that a target without hipcc still runs the scene-specialised kernels (rt_jit.hip looks there
+// before it forks a compiler).  `options`: "key=value key=value ..." as for rtpbr_set_option (jit, jit_bake, precision, ...).
+extern "C" int rtpbr_jit_prebuild(const rtpbr_object* objs, int n, int scale10, const rtpbr_config* cfg, const rtpbr_camera* cam,
+                                  int tile_w, int tile_h, int world, const char* options, char* path_out, size_t cap) {
+    if (!objs || !cfg || !cam) return fail(RTPBR_EINVAL, "rtpbr_jit_prebuild: scene, configuration and camera are required");
+    rtpbr_ctx ctx;
+    rtpbr_ctx* c = &ctx;
+    c->headless = true;
+    if (world > 1)
+        if (int r = rtpbr_set_tiles(c, tile_w, tile_h, 0, world)) return r;
+    if (int r = rtpbr_set_config(c, cfg)) return r;
+    if (int r = rtpbr_set_scene(c, objs, n, scale10)) return r;
+    if (int r = rtpbr_set_camera(c, cam)) return r;
+    std::string opt = options ? options : "";
+    for (size_t i = 0; i < opt.size();) {
+        while (i < opt.size() && opt[i] == ' ') i++;
+        size_t j = opt.find(' ', i);
+        if (j == std::string::npos) j = opt.size();
+        if (j > i) {
+            const std::string kv = opt.substr(i, j - i);
+            const size_t e = kv.find('=');
+            if (e == std::string::npos) return fail(RTPBR_EINVAL, "rtpbr_jit_prebuild: options are key=value pairs (%s)", kv.c_str());
+            if (int r = rtpbr_set_option(c, kv.substr(0, e).c_str(), atoll(kv.c_str() + e + 1))) return r;
+        }
+        i = j;
+    }
+    RtJitKey key{};
+    bool want = false, strict_error = false;
+    derive_launch(c, &key, &want, &strict_error);
+    if (!want) return fail(RTPBR_ESTATE, "rtpbr_jit_prebuild: with these options rtpbr_sample() would not use a run-time instance for this scene "
+                                         "(option jit, <= 8 analytic shapes or the neural shape with jit_bake, pool scheduler)");
+    std::string p;
+    if (int r = rt_jit_build(key, &p, nullptr)) return r;
+    if (path_out && cap) snprintf(path_out, cap, "%s", p.c_str());
+    return RTPBR_OK;
+}
+
 extern "C" int rtpbr_get_scene(rtpbr_ctx* c, rtpbr_object* objs, int n) {
     if (!c || !objs || n < 0 || n > c->n_obj) return fail(RTPBR_EINVAL, "bad get_scene arguments");
     memcpy(objs, c->obj, (size_t)n * sizeof *objs);
@@ -541,7 +591,15 @@ extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world
 int rt_order_after_reads(rtpbr_ctx* c, unsigned mask) {
     for (int b = 0; b < 5; b++)
         if (((mask >> b) & 1u) && c->read_pending[b] >= 0) {
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_read_done[c->read_pending[b] & 7], 0));
+            // (a copy that has landed already needs no ordering: a cross-stream wait is a barrier packet the command processor
+            // resolves in ~20 us — per frame that is what separates a pipelined viewer from the device-only rate — a query is ~1 us)
+            const hipError_t q = hipEventQuery(c->ev_read_done[c->read_pending[b] & 7]);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_read_done[c->read_pending[b] & 7], 0));
+            } else if (q != hipSuccess) {
+                return rt_fail_hip("hipEventQuery(read-back)", q);
+            }
             c->read_pending[b] = -1;
         }
     return RTPBR_OK;
@@ -620,13 +678,11 @@ static int trace_grid(rtpbr_ctx* c, uint32_t total_items) {
 // at most 32 waves per CU, at most 8192 items per claim (option "chunk" is clamped to that).
 static long long work_margin(const rtpbr_ctx* c) { return (long long)(c->n_cu > 0 ? c->n_cu : 256) * 32LL * 8192LL; }
 
-extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
-    if (!c) return fail(RTPBR_EINVAL, "null ctx");
-    if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
-    if (n < 0) return fail(RTPBR_EINVAL, "n must be >= 0");
-    if (int r = set_dev(c)) return r;
-    // (diff_buffer: instrumented builds write their per-wave records over it)
-    if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER)) return r;
+// Everything of a launch that is decided on the HOST from the context's state (configuration, scene, camera, tiles, options) and
+// that the run-time instance's key depends on: shared by rtpbr_sample() and rtpbr_jit_prebuild() (which has no device), so that
+// a code object compiled ahead of time for a catalog scene IS the one rtpbr_sample() will ask for.  *want = a run-time instance
+// is to be used (key filled); *strict_error = option jit = 2 and no instance exists for this scene.
+static void derive_launch(rtpbr_ctx* c, RtJitKey* key, bool* want, bool* strict_error) {
     Params& P = c->P;
     P.cfg = c->cfg;
     P.cam.inv_w = 1.0f / (float)c->cfg.width;
@@ -672,25 +728,45 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         P.cull_extent = 4.0f * ext;
     }
     box_thresholds(c->cfg.box_round, c->lazy_sqrt, P);
-    // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
-    rt_jit_release(c->jit_mod);
-    c->jit_mod = nullptr;
+    *want = false;
+    *strict_error = false;
     const bool jit_bunny = c->kind == KIND_BUNNY && c->jit_bake && c->jit >= 1;   // configuration baking only (incl. which units run the network)
     const bool persistent = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
     if (c->jit != 0 && (persistent || P.scheduler == 1) && c->n_obj <= 8 && (c->kind == KIND_BOXES || c->kind == KIND_GENERIC || (jit_bunny && !persistent))) {
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
         if (c->jit >= 1 || !aot_special || c->precision) {
-            const RtJitKey key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny, c->precision);
-            RtJitModule* jm = nullptr;
-            const int r = rt_jit_acquire(c, key, &jm);
-            if (r == RTPBR_OK) {
-                c->jit_mod = jm;
-                P.box_sig = key.sig;
-            } else if (c->jit == 2) {
-                return r;
-            }
+            *key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny, c->precision);
+            *want = true;
         }
     } else if (c->jit == 2) {
+        *strict_error = true;
+    }
+}
+
+extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
+    if (!c) return fail(RTPBR_EINVAL, "null ctx");
+    if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
+    if (n < 0) return fail(RTPBR_EINVAL, "n must be >= 0");
+    if (int r = set_dev(c)) return r;
+    // (diff_buffer: instrumented builds write their per-wave records over it)
+    if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER)) return r;
+    Params& P = c->P;
+    RtJitKey key{};
+    bool want_jit = false, strict_error = false;
+    derive_launch(c, &key, &want_jit, &strict_error);
+    // A run-time compiled instance of THIS scene (rt_jit.hip), when no listed ahead-of-time signature serves it
+    rt_jit_release(c->jit_mod);
+    c->jit_mod = nullptr;
+    if (want_jit) {
+        RtJitModule* jm = nullptr;
+        const int r = rt_jit_acquire(c, key, &jm);
+        if (r == RTPBR_OK) {
+            c->jit_mod = jm;
+            P.box_sig = key.sig;
+        } else if (c->jit == 2) {
+            return r;
+        }
+    } else if (strict_error) {
         return fail(RTPBR_ESTATE, "option jit = 2 (strict): no run-time instance exists for this scene (needs <= 8 analytic shapes, "
                                   "or the neural shape with jit_bake, and the pool scheduler)");
     }

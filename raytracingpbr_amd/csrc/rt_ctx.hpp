@@ -61,6 +61,7 @@ struct RtJitModule {
 };
 struct rtpbr_ctx;
 int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic);
+std::string rt_jit_catalog_dir();       // code objects shipped with the library (read-only; filled by `python -m raytracingpbr_amd.prebuild`)
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out);   // returns the instance pinned
 void rt_jit_release(RtJitModule* m);
 int rt_jit_launch(hipFunction_t f, const rt::Params& P, unsigned grid, hipStream_t st);
@@ -82,6 +83,7 @@ struct rtpbr_ctx {
     using Counters = rt::Counters;
     static constexpr int MAX_OBJ = rt::MAX_OBJ;
     int device = 0;
+    bool headless = false;            // no device behind this context (rtpbr_jit_prebuild): host-side state and derivations only
     hipStream_t stream = nullptr;
     bool have_cfg = false, have_scene = false, have_cam = false;
     rtpbr_config cfg{};

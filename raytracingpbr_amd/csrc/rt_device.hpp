@@ -1053,10 +1053,16 @@ RT_D vec3 sky_color(const Params& P, vec3 D) {
     if (P.cfg.sky_kind == RTPBR_SKY_ENVMAP && P.env != nullptr) {
         float u = atan2_(D.z, D.x) * INV_2PI + 0.5f;
         float v = asin_(D.y) * INV_PI + 0.5f;
-        int x = (int)(u * (float)P.env_w), y = (int)(v * (float)P.env_h);
-        x = x < 0 ? 0 : (x > P.env_w - 1 ? P.env_w - 1 : x);
-        y = y < 0 ? 0 : (y > P.env_h - 1 ? P.env_h - 1 : y);
-        float4 t = P.env[(size_t)x * P.env_h + y];
+        int ew = P.env_w, eh = P.env_h;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (the int -> float conversions stay HERE, one instruction each: hoisted out of a persistent kernel's main loop they hold two
+        // VGPRs for its whole length — the two registers the src/ pool kernel spilled to scratch, `Scratch_Size 12` in round 5's traces)
+        asm volatile("" : "+s"(ew), "+s"(eh));
+#endif
+        int x = (int)(u * (float)ew), y = (int)(v * (float)eh);
+        x = x < 0 ? 0 : (x > ew - 1 ? ew - 1 : x);
+        y = y < 0 ? 0 : (y > eh - 1 ? eh - 1 : y);
+        float4 t = P.env[(size_t)x * eh + y];
         return mk(t.x, t.y, t.z);
     }
     return mk(0, 0, 0);

@@ -100,11 +100,12 @@ bool source_hash(const std::string& dir, uint64_t* h) {
 
 // A code object from the cache: ONE descriptor, opened without following a symlink, that fstat() shows to be a regular
 // file owned by this user and not writable by group or others — what is checked is what is read.
-bool read_owned_file(const std::string& path, std::vector<char>& out) {
+// (or_root: a file of the CATALOG that ships with the library may also belong to root — whoever installed the package)
+bool read_owned_file(const std::string& path, std::vector<char>& out, bool or_root = false) {
     const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
     if (fd < 0) return false;
     struct stat st;
-    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && st.st_size > 0;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (st.st_uid == getuid() || (or_root && st.st_uid == 0)) && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && st.st_size > 0;
     if (ok) {
         out.resize((size_t)st.st_size);
         size_t got = 0;
@@ -203,6 +204,12 @@ int run(const std::vector<std::string>& argv, const std::string& log) {
 }
 }  // namespace
 
+// where the catalog lives: $RTPBR_JIT_CATALOG, else <library directory>/../data/jit
+std::string rt_jit_catalog_dir() {
+    if (const char* e = getenv("RTPBR_JIT_CATALOG")) return e;
+    return lib_dir() + "/../data/jit";
+}
+
 static uint64_t baked_hash(const RtJitKey& key) {
     if (!key.baked) return 0;
     uint64_t th = 1469598103934665603ull;
@@ -246,11 +253,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
     snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d%s_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
              key.cull, key.waves, key.form, key.fast ? "_fast" : "", (unsigned long long)th, (unsigned long long)sh);
     const std::string cdir = cache_dir();
-    if (cdir.empty())
-        return rt_fail(RTPBR_ESTATE, "run-time compilation is off: no cache directory that is owned by this user and closed to others "
-                                     "(tried $RTPBR_JIT_CACHE, else $XDG_CACHE_HOME/rtpbr or ~/.cache/rtpbr, then /tmp/rtpbr-cache-<uid>)%s", "");
     const std::string path = cdir + "/" + name + ".hsaco";
-    {
+    if (!cdir.empty()) {
         std::vector<char> probe;
         if (read_owned_file(path, probe)) {      // a cache hit must pass the same ownership test the loader applies
             (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);      // pruning is by mtime: make it follow use
@@ -258,6 +262,21 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
             return RTPBR_OK;
         }
     }
+    {
+        // the CATALOG shipped next to the library (raytracingpbr_amd/data/jit, read-only): code objects that
+        // __graft_entry__.build() / `python -m raytracingpbr_amd.prebuild` compiled ahead of time for the BASELINE scenes — same
+        // key, same name (the hash of the kernel sources is part of it: a stale catalog is never picked up).  A target without
+        // hipcc runs the scene-specialised kernels from here; nothing is ever written to it at run time.
+        const std::string shipped = rt_jit_catalog_dir() + "/" + name + ".hsaco";
+        std::vector<char> probe;
+        if (read_owned_file(shipped, probe, true)) {
+            *out = shipped;
+            return RTPBR_OK;
+        }
+    }
+    if (cdir.empty())
+        return rt_fail(RTPBR_ESTATE, "run-time compilation is off: no cache directory that is owned by this user and closed to others "
+                                     "(tried $RTPBR_JIT_CACHE, else $XDG_CACHE_HOME/rtpbr or ~/.cache/rtpbr, then /tmp/rtpbr-cache-<uid>)%s", "");
     static std::atomic<unsigned> g_build_seq{0};
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d.%u", (int)getpid(), g_build_seq.fetch_add(1u));
@@ -458,7 +477,8 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
         return r;
     }
     std::vector<char> image;
-    if (!read_owned_file(path, image)) {
+    const bool from_catalog = path.compare(0, rt_jit_catalog_dir().size() + 1, rt_jit_catalog_dir() + "/") == 0;
+    if (!read_owned_file(path, image, from_catalog)) {
         settle(nullptr, false, nullptr);
         return rt_fail(RTPBR_ESTATE, "cannot read %s (or it is not a private file of this user)", path.c_str());
     }
@@ -484,7 +504,7 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     if (e != hipSuccess) {
         if (m->module) (void)hipModuleUnload(m->module);
         delete m;
-        unlink(path.c_str());                        // a stale / truncated code object: the next call recompiles
+        if (!from_catalog) unlink(path.c_str());     // a stale / truncated code object: the next call recompiles (the catalog is read-only)
         settle(nullptr, false, nullptr);
         return rt_fail_hip("loading the run-time compiled code object", e);
     }

@@ -13,7 +13,7 @@ from raytracingpbr_amd.renderer import Renderer
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "librt_oracle.so")
-_OPTIONAL = ("host_alloc", "host_free", "buffer_device_ptr", "read_buffer_async", "read_wait", "packed_bytes", "pack_tiles", "unpack_tiles", "last_sample_ms", "last_primary_ms", "get_stream", "set_option",
+_OPTIONAL = ("host_alloc", "host_free", "buffer_device_ptr", "read_buffer_async", "read_wait", "jit_prebuild", "packed_bytes", "pack_tiles", "unpack_tiles", "last_sample_ms", "last_primary_ms", "get_stream", "set_option",
              "test_math", "rccl_unique_id", "rccl_init", "rccl_init_all", "gather_tiles", "gather_tiles_all", "rccl_info")
 
 _api = None

@@ -16,6 +16,14 @@ from raytracingpbr_amd import SHAPE, Config, Material, Renderer, Scene, SDFObjec
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _no_catalog(tmp_path, monkeypatch):
+    """These tests count the code objects the run-time compiler writes: hide the catalog compiled at build time
+    (raytracingpbr_amd/data/jit), which would serve some of their scenes without compiling anything."""
+    monkeypatch.setenv("RTPBR_JIT_CATALOG", str(tmp_path / "no-catalog"))
+
+
+
 def bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
@@ -217,3 +225,29 @@ def test_ranks_of_one_job_build_the_same_key_concurrently(tmp_path):
     assert len(crcs) == 1
     left = sorted(os.listdir(tmp_path))
     assert len([f for f in left if f.endswith(".hsaco")]) == 1 and not [f for f in left if ".tmp." in f], left
+
+
+def test_catalog_instance_runs_without_a_compiler(tmp_path, monkeypatch):
+    """A BASELINE scene on a target without hipcc (round 6): HIPCC points nowhere, the code-object cache is empty, option jit = 2
+    (strict: no fall-back to the ahead-of-time kernels) — the baked instance comes from the catalog compiled at build time
+    (raytracingpbr_amd/data/jit, rt_jit.hip) and its frame is the oracle's bit for bit; a scene that is not in the catalog is an
+    error in that situation, not a silent fall-back."""
+    from raytracingpbr_amd import workloads
+    from raytracingpbr_amd._capi import RtpbrError
+    monkeypatch.delenv("RTPBR_JIT_CATALOG", raising=False)
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    wl = workloads.get("c1")
+    g = Renderer(wl.scene, wl.cfg)
+    g.set_option("jit", 2); g.set_option("jit_bake", 2)
+    g.sample(wl.spp)
+    assert g.counter("jit_active") == 1 and not glob.glob(str(tmp_path / "*.hsaco"))
+    o = OracleRenderer(wl.scene, wl.cfg); o.sample(wl.spp)
+    assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer))
+    g.close()
+    wl = workloads.get("c1", 200, 120)
+    g = Renderer(wl.scene, wl.cfg)
+    g.set_option("jit", 2); g.set_option("jit_bake", 2)
+    with pytest.raises(RtpbrError):
+        g.sample(1)
+    g.close()

@@ -346,3 +346,26 @@ def test_c_abi_header_and_c_host_example_compile_as_plain_c(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.getsize(exe) > 8000
+
+
+def test_catalog_serves_the_baseline_scenes_without_a_compiler(tmp_path, monkeypatch):
+    """raytracingpbr_amd/prebuild.py + rt_jit.hip's catalog lookup (no GPU needed): with HIPCC pointing nowhere and an EMPTY
+    code-object cache, the key rtpbr_sample() would form for a BASELINE scene as bench.py sets it up resolves to the code
+    object compiled at build time (raytracingpbr_amd/data/jit); a scene that is not in the catalog fails loudly (no compiler),
+    and a hidden catalog makes the catalog scene fail the same way."""
+    from raytracingpbr_amd import prebuild
+    cat = prebuild.prebuild(prebuild.DEFAULT + prebuild.FAST)          # (a lookup per entry when build() has run; compiles otherwise)
+    assert len(cat) == len(prebuild.DEFAULT) + len(prebuild.FAST) and len(set(cat.values())) == len(cat)
+    assert all(os.path.dirname(os.path.realpath(p)) == os.path.realpath(prebuild.CATALOG_DIR) and os.path.getsize(p) > 10000 for p in cat.values())
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("RTPBR_JIT_CACHE", str(tmp_path))
+    lib = prebuild._lib()
+    for name, wl, dims, world, opts in (prebuild.DEFAULT[0], prebuild.DEFAULT[4], prebuild.DEFAULT[9], prebuild.DEFAULT[12], prebuild.FAST[0]):
+        got = prebuild.prebuild_one(lib, wl, dims, world, opts)
+        assert os.path.realpath(got) == os.path.realpath(cat[name]), name
+    assert not os.listdir(tmp_path)                                    # nothing was compiled, nothing was cached
+    with pytest.raises(RuntimeError):
+        prebuild.prebuild_one(lib, "c2", (800, 600), 1, "jit=1 jit_bake=2")     # not a catalog scene: needs the compiler
+    monkeypatch.setenv("RTPBR_JIT_CATALOG", str(tmp_path / "nowhere"))
+    with pytest.raises(RuntimeError):
+        prebuild.prebuild_one(lib, "c2", (0, 0), 1, "jit=1 jit_bake=2")
