@@ -270,6 +270,77 @@ def side_config(name, a, device, rank0_of=1):
     return out
 
 
+def tolerance_block(wl, a, device, torch):
+    """The tolerance flavour (option precision = 1) of the headline as a first-class, SELF-CHECKING result: measured with the same
+    --steps / --warmup as `value`, with its own roofline, and — outside the timed region, in this very run — held against the
+    exact kernels: both flavours render the same frame (same sample indices), the display-space per-pixel L2 between the two
+    image_pixels is computed ON THE DEVICE (rtpbr_buffer_device_ptr -> torch tensors on the renderers' own memory), and the flip
+    rate (samples whose colour differs beyond rounding) is counted on 16 single-sample frames.  The exact kernels are the
+    oracle's bits (tests/test_gpu_parity.py, test_gpu_fullsize.py), so this is the distance to the oracle's frame."""
+    from raytracingpbr_amd.renderer import BUF_IMAGE_BUFFER, BUF_IMAGE_PIXELS
+    W, H, SPP = wl.cfg.width, wl.cfg.height, wl.spp
+    rf = make_renderer(wl, device, a, jit=True)
+    rf.set_option("precision", 1)
+    rf.set_option("reserve_spp", SPP)
+    rf.sample(SPP)
+    rf.sync()
+    m = measure(wl, rf, a.steps, a.warmup)
+    c, fpu, kernel_s, tflops = roofline_of(wl, rf, m, a.steps, W * H)
+    out = {"what": "option precision = 1: hardware sqrt / rsq / rcp / exp, contraction, no exact decision bands (rt_math.hpp RT_FAST_MATH) — the regime the "
+                   "reference itself runs in (Taichi's default fast_math, src/config.py:5); held to the north star's per-pixel L2 < 1e-3; `value` above stays the exact kernels",
+           "value": round(W * H * SPP * a.steps / m["dt"] / 1e6, 2), "unit": wl.unit, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(m["dt"] / a.steps * 1e3, 3),
+           "roofline": {"bound": "valu", "achieved": round(tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4),
+                        "kernels": "rt_jit_primary + rt_jit_trace (tolerance flavour: LDS accumulators, no staging, no accumulate kernel)",
+                        "avg_launch_ms": round(m["trace_ms"] / max(m["launches"], 1), 3),
+                        "primary_rays_avg_launch_ms": round(m["primary_ms"] / max(m["primary_launches"], 1), 3),
+                        "algorithmic_flop_per_unit": round(fpu)},
+           "run_time_kernels": bool(rf.counter("jit_active"))}
+    # ---- the self-check (not timed): one frame of the same sample indices in both flavours, compared on the device
+    re = make_renderer(wl, device, a, jit=True)
+    re.set_option("reserve_spp", SPP)
+    for r in (re, rf):
+        r.refresh()
+        r.set_option("sample_base", 0)
+        r.sample(SPP)
+        r.post_process()
+        r.sync()
+    te = torch.as_tensor(re.device_array(BUF_IMAGE_PIXELS), device="cuda")
+    tf = torch.as_tensor(rf.device_array(BUF_IMAGE_PIXELS), device="cuda")
+    d = te.double() - tf.double()
+    out["l2_display_vs_exact"] = float(torch.sqrt(torch.mean(d * d)).item())
+    out["max_abs_pixel_difference"] = float(d.abs().max().item())
+    out["pixels_that_differ"] = float((d.abs().amax(dim=-1) > 0).double().mean().item())
+    out["bar"] = 1e-3
+    out["within_bar"] = bool(out["l2_display_vs_exact"] < 1e-3)
+    flips = total = 0
+    for k in range(16):
+        for r in (re, rf):
+            r.refresh()
+            r.set_option("sample_base", k)
+            r.sample(1)
+            r.sync()
+        ae = torch.as_tensor(re.device_array(BUF_IMAGE_BUFFER), device="cuda")[..., :3].double()
+        af = torch.as_tensor(rf.device_array(BUF_IMAGE_BUFFER), device="cuda")[..., :3].double()
+        dd = (ae - af).abs().amax(dim=-1)
+        tol = 1e-3 * torch.clamp(ae.abs().amax(dim=-1), min=1.0)
+        flips += int((dd > tol).sum().item())
+        total += dd.numel()
+    out["flip_rate"] = flips / total
+    out["flip_rate_note"] = f"{flips} of {total} samples (16 single-sample frames) whose colour differs from the exact kernels' by more than 1e-3 relative"
+    out["self_check"] = ("l2_display_vs_exact: both flavours rendered this frame (sample indices 0..spp-1) in this run, outside the timed region; the two image_pixels "
+                         "were compared on the device through rtpbr_buffer_device_ptr; the exact kernels are bit-identical with the CPU oracle (pytest -m gpu)")
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_fast.json")))
+        out["hbm"] = {"hbm_bytes_per_step": tj["fast"]["hbm_bytes_per_step"], "times_algorithmic": tj["fast"]["times_algorithmic"],
+                      "kind": "a COMMITTED constant from profiles/hbm_traffic_fast.json (separate FETCH_SIZE / WRITE_SIZE passes), not a measurement of this run"}
+    except Exception:
+        pass
+    re.close()
+    rf.close()
+    return out
+
+
 def frame_latency(a, device, W=768, H=432, frames=200):
     """One displayed frame the way the reference produces it (/root/reference src/renderer.py:25-32 + src/main.py:62-64):
     Renderer.render() = SAMPLES_PER_FRAME (1) x pathtrace() of ONE bounce-step + post_process(), then the host reads
@@ -607,9 +678,11 @@ def main():
                            "recompiles); camera_free_value = scene and configuration baked, camera a launch argument (jit_bake 1); unbaked_value = "
                            "run-time instance, nothing baked; aot_value = the ahead-of-time library alone (no hipcc on the target)")
             out["jit"] = jit
+            if a.workload == "c2" and not a.no_configs and not a.no_jit:
+                out["tolerance"] = tolerance_block(wl, a, local_rank, torch)
             if a.workload == "c2" and not a.no_configs:
                 out["configs"] = {n: side_config(n, a, local_rank) for n in ("c1", "c3", "c3_valu", "c4", "c5", "src", "src_768", "src_4k", "src_1step",
-                                                                                 "c2_fast", "c3_fast", "c4_fast", "src_fast")}
+                                                                                 "c3_fast", "c4_fast", "src_fast")}
             if a.workload == "c2" and not a.no_configs:
                 out["frame"] = frame_latency(a, local_rank)
             if not a.no_cpu_baseline:

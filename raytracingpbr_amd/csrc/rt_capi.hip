@@ -119,6 +119,8 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     if (c->ev_read_ready) (void)hipEventDestroy(c->ev_read_ready);
     for (hipEvent_t e : c->ev_read_done)
         if (e) (void)hipEventDestroy(e);
+    if (c->plan_rb_host) (void)hipHostFree(c->plan_rb_host);
+    if (c->ev_plan_rb) (void)hipEventDestroy(c->ev_plan_rb);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -743,6 +745,347 @@ static void derive_launch(rtpbr_ctx* c, RtJitKey* key, bool* want, bool* strict_
     }
 }
 
+static int launch_split_steps(rtpbr_ctx* c, int steps);
+// ------------------------------------------------------------------------------------------------------------------------
+// THE HOST SCHEDULER'S CONSTANTS, in one place.  Everything below that is a number was MEASURED on one MI355X (256 CUs, 4 SIMDs
+// per CU, 160 KB of LDS per CU); what follows from the device is read from hipDeviceProp (c->n_cu) or from the kernels'
+// occupancy (hipOccupancyMaxActiveBlocksPerMultiprocessor / the run-time module's own query).  Option defaults — the numbers a
+// caller can change — live in rt_ctx.hpp next to the option they belong to; rtpbr.h documents them.  On another SKU or a
+// partitioned device (CPX) these are the lines to re-measure (tools/gpu_src_grid.py, tools/gpu_src_1step.py sweep them).
+namespace tune {
+constexpr int WAVES_PER_BLOCK = 4;              // 256 threads: one wave per SIMD of a CU
+constexpr int CTX_PER_WAVE = 128;               // src/ pool kernel: 64 lanes + 64 LDS slots (rt_persistent.hpp)
+constexpr int MAX_FUSED_STEPS = 256;            // bounce-steps per fused src/ launch (G_META holds 9 bits)
+// --- src/ pool kernel (fused launches) -----------------------------------------------------------------------------------
+constexpr int POOL_MIN_PIX_PER_WAVE = 64;       // a wave never owns fewer pixels than it has lanes (grid <= np / 256)
+// beside the chain kernel a pool wave should own ~190 pixels, in whole blocks per CU, at least two (two waves of 162 contexts
+// march with 54-57 of 64 lanes, three of 108 with 34; a wave issues one instruction per ~6.5 cycles whatever it carries):
+// 1024x576 four -> three blocks per CU 30.8 -> 27.3 ms, 960x540 29.5 -> 24.2, 768x432 three -> two 22.7 -> 22.3 (round 5)
+constexpr int CHAIN_POOL_PIX_PER_BLOCK = 760;
+constexpr int CHAIN_POOL_MIN_BLOCKS_PER_CU = 2;
+constexpr int CHAIN_GRID_BLOCKS = 512;          // chain kernel: 2048 waves = the largest chain set a plan can make (waves without an entry leave at once)
+// --- src/ wavefront split (launches of <= src_split steps) -----------------------------------------------------------------
+// waves per SIMD of the march kernel: 2 / 3 / 4 / 5 / 8 = 0.53 / 0.51 / 0.51 / 0.55 / 0.59 ms per 1080p launch (the arbiter
+// serves the oldest wave first: with more the youngest starve and end last)
+constexpr int MARCH_MAX_BLOCKS_PER_CU = 4;
+// small frames are all tail: two waves per SIMD (640x360 0.230 / 0.236 / 0.240 ms at 2 / 3 / 4, 768x432 0.258 / 0.261 / 0.270,
+// no difference from 1024x576 on) and the list's heavy head interleaved over the groups (768x432 0.2375 -> 0.224; 1080p loses)
+constexpr long long MARCH_SMALL_FRAME_PIXELS = 600000;
+constexpr int MARCH_SMALL_BLOCKS_PER_CU = 2;
+constexpr int MARCH_MAX_TEAMS = 1024;           // team counters allocated (rtpbr_create)
+// --- complete-path form ----------------------------------------------------------------------------------------------------
+constexpr long long PRIMARY_SPLIT_MIN_ITEMS = 1LL << 23;    // the separate primary kernel costs ~0.3 ms per launch: below ~8 M items the fused kernel wins
+// work items a wave claims per atomic: total / (waves x 64) clamped to [256, 1024]; 128 when a launch has fewer than 256 per wave
+// (1080p x 16 spp: 64 / 128 / 256 / 512 items = 10.6 / 9.6 / 9.2 / 9.3 ms; 4096 cost 2 % on the Cornell frame and 18 % on the
+// glass bunny — a wave that claims the last chunk works it off 128 paths at a time; C1: 1407 -> 1492 Msamples/s with 128)
+constexpr long long CHUNK_MIN = 256, CHUNK_MAX = 1024, CHUNK_TINY = 128;
+constexpr int PRIMARY_BLOCKS_PER_CU = 8;        // the primary kernel needs ~57 VGPRs: 32 waves per CU
+}  // namespace tune
+
+// What the LAST plan decided about the chain set, learned asynchronously (a 4-byte copy behind the plan kernels): the pool
+// grid makes room for the chain kernel only when a plan actually produced one (advisor, round 5: the grid used to shrink
+// whenever the chain kernel was merely possible — uniform-cost scenes and the launches before the first plan then ran the
+// pool kernel alone on the reduced grid, measured slower: 36 against 26 ms at 768x432).
+static int poll_plan_readback(rtpbr_ctx* c) {
+    if (!c->plan_rb_pending) return RTPBR_OK;
+    const hipError_t q = hipEventQuery(c->ev_plan_rb);
+    if (q == hipSuccess) {
+        c->plan_chain_waves = (int)*c->plan_rb_host;
+        c->plan_rb_pending = false;
+    } else if (q != hipErrorNotReady) {
+        return rt_fail_hip("hipEventQuery(plan read-back)", q);
+    } else {
+        (void)hipGetLastError();
+    }
+    return RTPBR_OK;
+}
+
+// src/ persistent-ray form: n launches of pathtrace() (src/renderer.py:29-30), each cfg.steps_per_launch bounce-steps.
+// A pixel's steps are sequential and the RNG is keyed by the absolute step index, so k launches of s steps equal one launch of
+// k*s steps bit for bit: fuse them (<= 256 steps per kernel) instead of paying a launch + an 80 B/pixel ray_buffer round
+// trip per step.
+static int sample_persistent(rtpbr_ctx* c, int n) {
+    Params& P = c->P;
+    long long left = (long long)n * c->cfg.steps_per_launch;
+    while (left > 0) {
+        int steps = (int)(left < tune::MAX_FUSED_STEPS ? left : tune::MAX_FUSED_STEPS);
+        P.sample_base = c->sample_base;
+        NEXT_EVENT(c->ev, c->ev_used, a);
+        NEXT_EVENT(c->ev, c->ev_used, b);
+        HIP_TRY(hipEventRecord(a, c->stream));
+        // pool scheduler unless asked otherwise: measured faster than one lane per pixel at every frame size from
+        // 256x256 up (profiles/r03_src_*; round 2 switched at 2^20 pixels by a guess)
+        const bool use_pool = c->scheduler != 0;
+        if (use_pool) {
+            // Static ownership (persistent_pool_impl): every resident wave owns np / waves pixels.  A wave holds 128 contexts:
+            // when the frame fits (np <= 128 x resident waves) the grid is sized so that every wave owns <= 128 pixels and
+            // keeps them for the whole launch, in whole multiples of the CU count (every CU the same number of blocks), but
+            // never fewer than 64 pixels per wave; larger frames use every resident wave and walk their pixels in
+            // residencies of `residency` bounce-steps.
+            int per_cu = c->jit_mod ? c->jit_mod->persistent_blocks_per_cu : persistent_pool_blocks_per_cu(c->kind);
+            if (per_cu <= 0) per_cu = 2;
+            if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
+            const long long max_blocks = (long long)per_cu * c->n_cu;
+            const long long ctx_per_block = (long long)tune::CTX_PER_WAVE * tune::WAVES_PER_BLOCK;
+            long long grid = ((long long)P.np + ctx_per_block - 1) / ctx_per_block;
+            if (grid >= max_blocks) {
+                grid = max_blocks;
+            } else {
+                grid = (grid + c->n_cu - 1) / c->n_cu * c->n_cu;
+                if (grid > max_blocks) grid = max_blocks;
+                const long long dense = (long long)P.np / (tune::POOL_MIN_PIX_PER_WAVE * tune::WAVES_PER_BLOCK);
+                if (grid > dense) grid = dense;
+            }
+            const long long grid_alone = grid < 1 ? 1 : grid;      // the pool kernel's grid when nothing runs beside it
+            // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel and needs wave slots of its own.  Frames up to about
+            // 1080p may be chain-bound (plan_scan decides, on the device, against the grid the pool kernel would have ALONE);
+            // when the last plan made a chain set the pool grid makes room — whole multiples of the CU count: an uneven grid
+            // costs more than it gives (1024x576 42.8 -> 30 ms, 1280x720 46 -> 40, 1600x900 54.7 -> 50.4, 1080p 58.6 -> 57.3) —
+            // and is sized for ~190 pixels per wave.  Larger frames are throughput-bound and keep the whole device for the pool
+            // kernel (2560x1440: 97.2 against 100.3 ms).
+            if (int r = poll_plan_readback(c)) return r;
+            const long long chain_blocks = (c->chain_waves + tune::WAVES_PER_BLOCK - 1) / tune::WAVES_PER_BLOCK;
+            const bool chain_candidate = c->src_chain != 0 && c->grid_blocks == 0 && c->src_plan && (long long)P.np <= c->chain_np_max;
+            const bool chain_room = chain_candidate && (c->plan_chain_waves > 0 || c->src_chain == 2);
+            if (chain_room) {
+                if (grid + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu) grid = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
+                long long want = ((long long)P.np / tune::CHAIN_POOL_PIX_PER_BLOCK + c->n_cu / 2) / c->n_cu * c->n_cu;
+                if (want < (long long)tune::CHAIN_POOL_MIN_BLOCKS_PER_CU * c->n_cu) want = (long long)tune::CHAIN_POOL_MIN_BLOCKS_PER_CU * c->n_cu;
+                if (grid > want) grid = want;
+            }
+            if (c->grid_blocks > 0) grid = c->grid_blocks;
+            if (grid < 1) grid = 1;
+            P.total_items = (uint32_t)P.np;
+            P.chunk = (uint32_t)c->residency;                               // bounce-steps per residency (a power of two)
+            // Cost-ordered ownership: the kernel records every pixel's march steps; once plan_interval bounce-steps
+            // are on record the pixels are re-ordered by them (three small kernels on the same stream) and the
+            // heaviest get waves of their own.  The plan survives refresh(): what a pixel costs is a property of
+            // the scene and the camera, not of the accumulated image.
+            P.cost_buffer = nullptr;
+            P.order = nullptr;
+            P.plan = nullptr;
+            P.heavy_own = c->heavy_own;
+            P.heavy_prio = c->heavy_prio;
+            P.src_track = c->src_track;
+            P.src_op = c->src_op;
+            P.leave_x8 = c->leave_x8;
+            P.tiny_own = c->tiny_own;
+            P.n_cu = c->n_cu;
+            P.age_on = c->age_on;
+            P.age_pack = 0;
+            for (int k = 0; k < 8; k++) P.age_pack |= (uint32_t)(c->age_w[k] & 15) << (4 * k);
+            // the chain kernel is launched only when the device has room for both: more resident waves than it holds just queue
+            // the pool's last blocks behind the chain waves (measured -12 % at 720p)
+            const bool chain_fits = chain_candidate && grid + chain_blocks <= max_blocks;
+            const bool chain_eff = c->src_chain != 0 && (chain_fits || c->src_chain == 2);
+            if (c->src_plan) {
+                if (c->plan_np != (size_t)P.np) {
+                    HIP_TRY(hipStreamSynchronize(c->stream));
+                    (void)hipFree(c->cost_buffer);
+                    (void)hipFree(c->order);
+                    c->cost_buffer = c->order = nullptr;
+                    c->plan_np = 0;
+                    c->order_valid = false;
+                    c->cost_steps = 0;
+                    c->plan_chain_waves = 0;
+                    c->plan_rb_pending = false;
+                    HIP_TRY(hipMalloc(&c->cost_buffer, (size_t)P.np * sizeof(uint32_t)));
+                    HIP_TRY(hipMalloc(&c->order, (size_t)P.np * sizeof(uint32_t)));
+                    if (!c->plan) {
+                        HIP_TRY(hipMalloc(&c->plan, sizeof(PlanBuf)));
+                        HIP_TRY(hipMemsetAsync(c->plan, 0, sizeof(PlanBuf), c->stream));
+                    }
+                    HIP_TRY(hipMemsetAsync(c->cost_buffer, 0, (size_t)P.np * sizeof(uint32_t), c->stream));
+                    c->plan_np = (size_t)P.np;
+                }
+                if (c->cost_steps >= c->plan_interval) {
+                    // (the plan sizes its heavy waves for THIS launch's grid and decides "chain-bound" against the grid the pool
+                    // kernel has alone: the decision does not depend on whether room has been made already)
+                    launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
+                                c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), chain_candidate || c->src_chain == 2 ? c->chain_waves : 0,
+                                (uint32_t)grid_alone * 4u, c->stream);
+                    c->order_valid = true;
+                    c->cost_steps = 0;
+                    if (!c->plan_rb_host) {
+                        HIP_TRY(hipHostMalloc((void**)&c->plan_rb_host, 64, hipHostMallocDefault));
+                        HIP_TRY(hipEventCreateWithFlags(&c->ev_plan_rb, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipMemcpyAsync(c->plan_rb_host, &c->plan->n_chain_waves, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(hipEventRecord(c->ev_plan_rb, c->stream));
+                    c->plan_rb_pending = true;
+                }
+                P.cost_buffer = c->cost_buffer;
+                P.order = c->order_valid ? c->order : nullptr;
+                P.plan = c->plan;
+                c->cost_steps += steps;
+            }
+            if (c->src_split > 0 && steps <= c->src_split) {
+                if (int r = launch_split_steps(c, steps)) return r;
+            } else {
+                // A chain-bound launch hands the head of the cost-ordered list to the chain kernel (rt_chain.hpp), which runs
+                // BESIDE the pool kernel on a second stream: forked after the plan, joined before anything else touches the
+                // buffers.  Its grid covers the largest chain set a plan can make; waves without an entry leave at once.
+                P.chain_on = (chain_eff && P.order) ? 1 : 0;
+                bool forked = false;
+                int rc = RTPBR_OK;
+                if (P.chain_on) {
+                    if (!c->stream2) {
+                        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+                    HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+                    forked = true;
+                    if (c->jit_mod)
+                        rc = rt_jit_launch_steps(c->jit_mod->chain_steps, P, steps, (unsigned)tune::CHAIN_GRID_BLOCKS, c->stream2);
+                    else
+                        launch_chain_steps(P, c->kind, steps, tune::CHAIN_GRID_BLOCKS, c->stream2);
+                }
+                if (rc == RTPBR_OK) {
+                    if (c->jit_mod)
+                        rc = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream);
+                    else
+                        launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
+                }
+                // JOIN on every exit once the second stream has been forked (advisor, round 5): nothing that follows on the
+                // context's stream may overtake a chain kernel that is still running — if the event cannot be recorded, wait
+                // for the stream itself
+                if (forked) {
+                    if (hipEventRecord(c->ev_join, c->stream2) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_join, 0) != hipSuccess) {
+                        (void)hipGetLastError();
+                        (void)hipStreamSynchronize(c->stream2);
+                    }
+                }
+                P.chain_on = 0;      // (persistent state of the context: only this launch ran with the chain set split off)
+                if (rc != RTPBR_OK) return rc;
+            }
+        } else if (c->jit_mod) {
+            if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
+        } else
+            launch_persistent(P, c->kind, steps, c->stream);
+        HIP_TRY(hipEventRecord(b, c->stream));
+        c->sample_base += (uint32_t)steps;
+        left -= steps;
+    }
+    return RTPBR_OK;
+}
+
+// A launch of one (or a few) bounce-steps — the way the reference calls pathtrace(), src/renderer.py:29-30 — as the wavefront
+// split of rt_split.hpp: per step gen (roulette / deposit / camera ray), march (the raycasts, heaviest first from the
+// cost-ordered list), shade.  Same results, same counters as the fused kernels.
+static int launch_split_steps(rtpbr_ctx* c, int steps) {
+    Params& P = c->P;
+    if (c->march_np != (size_t)P.np) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->march_out);
+        c->march_out = nullptr;
+        c->march_np = 0;
+        HIP_TRY(hipMalloc(&c->march_out, (size_t)P.np * sizeof(uint32_t)));
+        c->march_np = (size_t)P.np;
+    }
+    P.march_out = c->march_out;
+    P.wait_lanes = c->split_wait;
+    P.chain_on = 0;
+    int mper = c->jit_mod ? c->jit_mod->march_blocks_per_cu : src_march_blocks_per_cu(c->kind);
+    if (mper <= 0) mper = 2;
+    if (mper > tune::MARCH_MAX_BLOCKS_PER_CU) mper = tune::MARCH_MAX_BLOCKS_PER_CU;
+    const bool small = (long long)P.np <= tune::MARCH_SMALL_FRAME_PIXELS;
+    if (small && mper > tune::MARCH_SMALL_BLOCKS_PER_CU) mper = tune::MARCH_SMALL_BLOCKS_PER_CU;
+    P.split_head = c->split_head >= 0 ? c->split_head : (small ? 1 : 0);
+    if (c->waves_per_cu > 0) mper = (c->waves_per_cu + 3) / 4;
+    long long mgrid = (long long)mper * c->n_cu;
+    const long long need = ((long long)P.np + 255) / 256;
+    if (mgrid > need) mgrid = need;
+    if (c->grid_blocks > 0) mgrid = c->grid_blocks;
+    if (mgrid < 1) mgrid = 1;
+    // teams of blocks that share a claim counter: the blocks resident on one CU (blocks are placed round-robin)
+    P.team_counter = c->team_counter;
+    P.n_teams = (int)(mgrid < c->n_cu ? mgrid : c->n_cu);
+    if (P.n_teams > tune::MARCH_MAX_TEAMS) P.n_teams = tune::MARCH_MAX_TEAMS;
+    for (int i = 0; i < steps; i++) {
+        P.sample_base = c->sample_base + (uint32_t)i;
+        if (c->jit_mod) {
+            if (int r = rt_jit_launch(c->jit_mod->src_gen, P, (unsigned)need, c->stream)) return r;
+            if (int r = rt_jit_launch(c->jit_mod->src_march, P, (unsigned)mgrid, c->stream)) return r;
+            if (int r = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)need, c->stream)) return r;
+        } else {
+            launch_src_gen(P, c->kind, c->stream);
+            launch_src_march(P, c->kind, (int)mgrid, c->stream);
+            launch_src_shade(P, c->kind, c->stream);
+        }
+    }
+    return RTPBR_OK;
+}
+
+// complete-path form: `n` samples per owned pixel (the spp loop of cornell_box_v3/renderer.py:31-36), in sub-launches of as
+// many samples per pixel as the staging budget holds
+static int sample_complete_path(rtpbr_ctx* c, int n) {
+    Params& P = c->P;
+    int left = n;
+    while (left > 0) {
+        const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
+        // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
+        const bool unstaged = c->precision != 0 && c->jit_mod != nullptr && P.scheduler == 1;
+        long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
+        if (per_spp < 1) per_spp = 1;
+        long long kmax = c->staging_bytes / per_spp;
+        if (kmax < 1) kmax = 1;
+        // keep total_items within 32 bits (minus the chunks the last waves claim past the end: the work counter must not wrap)
+        long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)P.np;
+        if (k32 < 1) k32 = 1;
+        if (kmax > k32) kmax = k32;
+        int K = (int)(left < kmax ? left : kmax);
+        const bool split = split_ok && (c->primary_split == 2 || (long long)P.np * K >= tune::PRIMARY_SPLIT_MIN_ITEMS);
+        if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split, !unstaged)) {
+            // no room for K samples per launch: halve the budget and go round again (1 spp per launch must fit)
+            if (r != RTPBR_ENOMEM || K == 1)
+                return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "no device memory for the staging of one sample per pixel") : r;
+            c->staging_bytes = (long long)((K + 1) / 2) * per_spp;
+            continue;
+        }
+        P.primary = c->primary;
+        P.primary_split = split ? 1 : 0;
+        P.primary_lean = c->primary_lean;
+        P.drain_lanes = c->drain_lanes;
+        P.stage = c->stage;
+        P.K = K;
+        P.sample_base = c->sample_base;
+        P.total_items = (uint32_t)((long long)P.np * K);
+        int grid = trace_grid(c, P.total_items);
+        long long waves = (long long)grid * tune::WAVES_PER_BLOCK;
+        long long chunk = (long long)P.total_items / (waves * 64);
+        if (chunk < tune::CHUNK_MIN) chunk = (long long)P.total_items < waves * tune::CHUNK_MIN ? tune::CHUNK_TINY : tune::CHUNK_MIN;
+        if (chunk > tune::CHUNK_MAX) chunk = tune::CHUNK_MAX;
+        if (c->chunk > 0) chunk = c->chunk;
+        P.chunk = (uint32_t)chunk;
+        HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
+        if (split) {
+            NEXT_EVENT(c->evp, c->evp_used, pa);
+            NEXT_EVENT(c->evp, c->evp_used, pb);
+            HIP_TRY(hipEventRecord(pa, c->stream));
+            if (c->jit_mod) {
+                long long need = ((long long)P.total_items + 255) / 256, pg = (long long)c->n_cu * tune::PRIMARY_BLOCKS_PER_CU;
+                if (int r = rt_jit_launch(c->jit_mod->primary, P, (unsigned)(pg < need ? pg : need), c->stream)) return r;
+            } else
+                launch_primary(P, c->kind, c->n_cu, c->stream);
+            HIP_TRY(hipEventRecord(pb, c->stream));
+        }
+        NEXT_EVENT(c->ev, c->ev_used, a);
+        NEXT_EVENT(c->ev, c->ev_used, b);
+        HIP_TRY(hipEventRecord(a, c->stream));
+        if (c->jit_mod) {
+            if (int r = rt_jit_launch(c->jit_mod->trace, P, (unsigned)grid, c->stream)) return r;
+        } else
+            launch_trace(P, c->kind, grid, c->stream);
+        HIP_TRY(hipEventRecord(b, c->stream));
+        if (!unstaged) launch_accumulate(P, c->stream);
+        c->sample_base += (uint32_t)K;
+        left -= K;
+    }
+    return RTPBR_OK;
+}
+
 extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (!c->have_cfg || !c->have_scene || !c->have_cam) return fail(RTPBR_ESTATE, "set_config, set_scene and set_camera first");
@@ -784,271 +1127,9 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     c->timed = true;
     HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
     if (c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY) {
-        // n launches of pathtrace() (src/renderer.py:29-30), each cfg.steps_per_launch bounce-steps.
-        // A pixel's steps are sequential and the RNG is keyed by the absolute step index, so k
-        // launches of s steps equal one launch of k*s steps bit for bit: fuse them (<= 256 steps
-        // per kernel) instead of paying a launch + an 80 B/pixel ray_buffer round trip per step.
-        long long left = (long long)n * c->cfg.steps_per_launch;
-        while (left > 0) {
-            int steps = (int)(left < 256 ? left : 256);
-            P.sample_base = c->sample_base;
-            NEXT_EVENT(c->ev, c->ev_used, a);
-            NEXT_EVENT(c->ev, c->ev_used, b);
-            HIP_TRY(hipEventRecord(a, c->stream));
-            // pool scheduler unless asked otherwise: measured faster than one lane per pixel at every frame size from
-            // 256x256 up (profiles/r03_src_*; round 2 switched at 2^20 pixels by a guess)
-            const bool use_pool = c->scheduler != 0;
-            if (use_pool) {
-                // Static strided ownership (persistent_pool_impl): every resident wave owns np / waves pixels.  A wave
-                // holds 128 contexts (64 lanes + 64 slots): when the frame fits (np <= 128 x resident waves) the grid is
-                // sized so that every wave owns <= 128 pixels and keeps them for the whole launch, in whole multiples of
-                // the CU count (every CU the same number of blocks), but never fewer than 64 pixels per wave; larger
-                // frames use every resident wave and walk their pixels in residencies of `residency` bounce-steps.
-                int per_cu = c->jit_mod ? c->jit_mod->persistent_blocks_per_cu : persistent_pool_blocks_per_cu(c->kind);
-                if (per_cu <= 0) per_cu = 2;
-                if (c->waves_per_cu > 0) per_cu = (c->waves_per_cu + 3) / 4;
-                const long long max_blocks = (long long)per_cu * c->n_cu;
-                long long grid = ((long long)P.np + 511) / 512;                 // 128 contexts per wave, 4 waves per block
-                if (grid >= max_blocks) {
-                    grid = max_blocks;
-                } else {
-                    grid = (grid + c->n_cu - 1) / c->n_cu * c->n_cu;
-                    if (grid > max_blocks) grid = max_blocks;
-                    const long long dense = (long long)P.np / 256;              // >= 64 pixels per wave
-                    if (grid > dense) grid = dense;
-                }
-                // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel and needs wave slots of its own.  Frames up to about
-                // 1080p are (or may be) chain-bound — measured with the chain set beside a pool grid of four blocks per CU instead of
-                // five: 1024x576 42.8 -> 30 ms, 1280x720 46 -> 40, 1600x900 54.7 -> 50.4, 1080p 58.6 -> 57.3 — so there the pool
-                // grid makes room (whole multiples of the CU count: an uneven grid costs more than it gives).  Larger frames are
-                // throughput-bound and keep the whole device for the pool kernel (2560x1440: 97.2 against 100.3 ms).
-                const long long chain_blocks = (c->chain_waves + 3) / 4;
-                const bool chain_want = c->src_chain != 0 && c->grid_blocks == 0 && c->src_plan && (long long)P.np <= c->chain_np_max;
-                if (chain_want && grid + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu)
-                    grid = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
-                // Beside the chain kernel a pool wave should own ~190 pixels, in whole blocks per CU, never fewer than two waves per
-                // SIMD.  A small frame has a fixed number of contexts per SIMD (324 at 768x432): three waves of 108 march with 34 of
-                // their 64 lanes, two waves of 162 with 54-57 (per-wave records, tools/gpu_pool_simd.py) — and a wave issues one
-                // instruction per ~6.5 cycles however many lanes it carries, so lane-steps per SIMD cycle are 2 / 6.5 x 57 against
-                // 3 / 7.8 x 36.  Measured, ms per 256 steps: 1024x576 four -> three blocks per CU 30.8 -> 27.3, 960x540 29.5 -> 24.2,
-                // 768x432 three -> two 22.7 -> 22.3; one block per CU 37 (one wave cannot hide its own latencies); without the
-                // chain kernel the heaviest pixels need the larger grid: 26 against 36 at 768x432.
-                if (chain_want) {
-                    long long want = ((long long)P.np / 760 + c->n_cu / 2) / c->n_cu * c->n_cu;
-                    if (want < 2LL * c->n_cu) want = 2LL * c->n_cu;
-                    if (grid > want) grid = want;
-                }
-                if (c->grid_blocks > 0) grid = c->grid_blocks;
-                if (grid < 1) grid = 1;
-                P.total_items = (uint32_t)P.np;
-                P.chunk = (uint32_t)c->residency;                               // bounce-steps per residency (a power of two)
-                // Cost-ordered ownership: the kernel records every pixel's march steps; once plan_interval bounce-steps
-                // are on record the pixels are re-ordered by them (three small kernels on the same stream) and the
-                // heaviest get waves of their own.  The plan survives refresh(): what a pixel costs is a property of
-                // the scene and the camera, not of the accumulated image.
-                P.cost_buffer = nullptr;
-                P.order = nullptr;
-                P.plan = nullptr;
-                P.heavy_own = c->heavy_own;
-                P.heavy_prio = c->heavy_prio;
-                P.src_track = c->src_track;
-                P.src_op = c->src_op;
-                P.leave_x8 = c->leave_x8;
-                P.tiny_own = c->tiny_own;
-                P.n_cu = c->n_cu;
-                P.age_on = c->age_on;
-                P.age_pack = 0;
-                for (int k = 0; k < 8; k++) P.age_pack |= (uint32_t)(c->age_w[k] & 15) << (4 * k);
-                // (only when the device has room for both: more resident waves than it holds just queue the pool's last blocks
-                // behind the chain waves, measured -12 % at 720p)
-                const bool chain_fits = chain_want && grid + chain_blocks <= max_blocks;
-                const bool chain_eff = c->src_chain != 0 && (chain_fits || c->src_chain == 2);
-                if (c->src_plan) {
-                    if (c->plan_np != (size_t)P.np) {
-                        HIP_TRY(hipStreamSynchronize(c->stream));
-                        (void)hipFree(c->cost_buffer);
-                        (void)hipFree(c->order);
-                        c->cost_buffer = c->order = nullptr;
-                        c->plan_np = 0;
-                        c->order_valid = false;
-                        c->cost_steps = 0;
-                        HIP_TRY(hipMalloc(&c->cost_buffer, (size_t)P.np * sizeof(uint32_t)));
-                        HIP_TRY(hipMalloc(&c->order, (size_t)P.np * sizeof(uint32_t)));
-                        if (!c->plan) {
-                            HIP_TRY(hipMalloc(&c->plan, sizeof(PlanBuf)));
-                            HIP_TRY(hipMemsetAsync(c->plan, 0, sizeof(PlanBuf), c->stream));
-                        }
-                        HIP_TRY(hipMemsetAsync(c->cost_buffer, 0, (size_t)P.np * sizeof(uint32_t), c->stream));
-                        c->plan_np = (size_t)P.np;
-                    }
-                    if (c->cost_steps >= c->plan_interval) {
-                        launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
-                                    c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), chain_eff ? c->chain_waves : 0, c->stream);
-                        c->order_valid = true;
-                        c->cost_steps = 0;
-                    }
-                    P.cost_buffer = c->cost_buffer;
-                    P.order = c->order_valid ? c->order : nullptr;
-                    P.plan = c->plan;
-                    c->cost_steps += steps;
-                }
-                // A launch of one (or a few) bounce-steps — the way the reference calls pathtrace(), src/renderer.py:29-30 — runs
-                // as the wavefront split of rt_split.hpp: per step gen (roulette / deposit / camera ray), march (the raycasts,
-                // heaviest first from the cost-ordered list), shade.  Same results, same counters.
-                if (c->src_split > 0 && steps <= c->src_split) {
-                    if (c->march_np != (size_t)P.np) {
-                        HIP_TRY(hipStreamSynchronize(c->stream));
-                        (void)hipFree(c->march_out);
-                        c->march_out = nullptr;
-                        c->march_np = 0;
-                        HIP_TRY(hipMalloc(&c->march_out, (size_t)P.np * sizeof(uint32_t)));
-                        c->march_np = (size_t)P.np;
-                    }
-                    P.march_out = c->march_out;
-                    P.wait_lanes = c->split_wait;
-                    int mper = c->jit_mod ? c->jit_mod->march_blocks_per_cu : src_march_blocks_per_cu(c->kind);
-                    if (mper <= 0) mper = 2;
-                    // four waves per SIMD: with more the youngest starve (the arbiter serves the oldest wave first) and end last;
-                    // measured at 1080p: 2 / 3 / 4 / 5 / 8 waves = 0.53 / 0.51 / 0.51 / 0.55 / 0.59 ms per launch
-                    if (mper > 4) mper = 4;
-                    // (small frames are all tail: two waves per SIMD — 2 / 3 / 4 at 640x360 0.230 / 0.236 / 0.240 ms per launch, 768x432
-                    // 0.258 / 0.261 / 0.270, 960x540 0.287 / 0.289 / 0.292; no difference from 1024x576 on)
-                    if ((long long)P.np <= 600000 && mper > 2) mper = 2;
-                    // ... and there the heavy head of the list is interleaved over the groups (rt_split.hpp: 768x432 0.2375 -> 0.224 ms
-                    // per launch; at 1080p, four waves per SIMD, 0.469 -> 0.478: kept as it was)
-                    P.split_head = c->split_head >= 0 ? c->split_head : ((long long)P.np <= 600000 ? 1 : 0);
-                    if (c->waves_per_cu > 0) mper = (c->waves_per_cu + 3) / 4;
-                    long long mgrid = (long long)mper * c->n_cu;
-                    const long long need = ((long long)P.np + 255) / 256;
-                    if (mgrid > need) mgrid = need;
-                    if (c->grid_blocks > 0) mgrid = c->grid_blocks;
-                    if (mgrid < 1) mgrid = 1;
-                    // teams of blocks that share a claim counter: the blocks resident on one CU (blocks are placed round-robin)
-                    P.team_counter = c->team_counter;
-                    P.n_teams = (int)(mgrid < c->n_cu ? mgrid : c->n_cu);
-                    if (P.n_teams > 1024) P.n_teams = 1024;
-                    for (int i = 0; i < steps; i++) {
-                        P.sample_base = c->sample_base + (uint32_t)i;
-                        if (c->jit_mod) {
-                            if (int r = rt_jit_launch(c->jit_mod->src_gen, P, (unsigned)need, c->stream)) return r;
-                            if (int r = rt_jit_launch(c->jit_mod->src_march, P, (unsigned)mgrid, c->stream)) return r;
-                            if (int r = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)need, c->stream)) return r;
-                        } else {
-                            launch_src_gen(P, c->kind, c->stream);
-                            launch_src_march(P, c->kind, (int)mgrid, c->stream);
-                            launch_src_shade(P, c->kind, c->stream);
-                        }
-                    }
-                } else {
-                    // A chain-bound launch (plan_scan decides, on the device) hands the head of the cost-ordered list to the chain
-                    // kernel (rt_chain.hpp), which runs BESIDE the pool kernel on a second stream: forked after the plan, joined
-                    // before anything else touches the buffers.  Its grid covers the largest chain set a plan can make; waves
-                    // without an entry leave at once.
-                    P.chain_on = (chain_eff && P.order) ? 1 : 0;
-                    if (P.chain_on) {
-                        if (!c->stream2) {
-                            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-                            HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                            HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-                        }
-                        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-                        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-                        const int cgrid = 512;       // 2048 waves: the largest chain set (the plan may be older than this launch's grid)
-                        if (c->jit_mod) {
-                            if (int r = rt_jit_launch_steps(c->jit_mod->chain_steps, P, steps, (unsigned)cgrid, c->stream2)) return r;
-                        } else
-                            launch_chain_steps(P, c->kind, steps, cgrid, c->stream2);
-                        HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-                    }
-                    int pool_rc = RTPBR_OK;
-                    if (c->jit_mod)
-                        pool_rc = rt_jit_launch_steps(c->jit_mod->persistent_pool, P, steps, (unsigned)grid, c->stream);
-                    else
-                        launch_persistent_pool(P, c->kind, steps, (int)grid, c->stream);
-                    // (joined whatever happened to the pool launch: nothing that follows on the context's stream may overtake the chain kernel)
-                    if (P.chain_on) HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-                    if (pool_rc != RTPBR_OK) return pool_rc;
-                }
-            } else if (c->jit_mod) {
-                if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
-            } else
-                launch_persistent(P, c->kind, steps, c->stream);
-            HIP_TRY(hipEventRecord(b, c->stream));
-            c->sample_base += (uint32_t)steps;
-            left -= steps;
-        }
+        if (int r = sample_persistent(c, n)) return r;
     } else {
-        int left = n;
-        while (left > 0) {
-            const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
-            // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
-            const bool unstaged = c->precision != 0 && c->jit_mod != nullptr && P.scheduler == 1;
-            long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
-            if (per_spp < 1) per_spp = 1;
-            long long kmax = c->staging_bytes / per_spp;
-            if (kmax < 1) kmax = 1;
-            // keep total_items within 32 bits
-            // (minus the chunks the last waves claim past the end: the work counter must not wrap)
-            long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)P.np;
-            if (k32 < 1) k32 = 1;
-            if (kmax > k32) kmax = k32;
-            int K = (int)(left < kmax ? left : kmax);
-            // the extra launch has a fixed cost of ~0.3 ms: below ~8 M items the fused kernel is faster
-            const bool split = split_ok && (c->primary_split == 2 || (long long)P.np * K >= (1LL << 23));
-            if (int r = ensure_staging(c, (size_t)P.np * (size_t)K, split, !unstaged)) {
-                // no room for K samples per launch: halve the budget and go round again (1 spp per launch must fit)
-                if (r != RTPBR_ENOMEM || K == 1)
-                    return r == RTPBR_ENOMEM ? fail(RTPBR_ENOMEM, "no device memory for the staging of one sample per pixel") : r;
-                c->staging_bytes = (long long)((K + 1) / 2) * per_spp;
-                continue;
-            }
-            P.primary = c->primary;
-            P.primary_split = split ? 1 : 0;
-            P.primary_lean = c->primary_lean;
-            P.drain_lanes = c->drain_lanes;
-            P.stage = c->stage;
-            P.K = K;
-            P.sample_base = c->sample_base;
-            P.total_items = (uint32_t)((long long)P.np * K);
-            int grid = trace_grid(c, P.total_items);
-            long long waves = (long long)grid * 4;
-            // the last chunk a wave claims is the launch's tail (<= 1/64 of a wave's work), but a claim stalls the wave for
-            // an atomic's round trip and scatters its reads of the primary records: below 256 items the loss grows
-            // (1080p x 16 spp: 64 / 128 / 256 / 512 items = 10.6 / 9.6 / 9.2 / 9.3 ms)
-            long long chunk = (long long)P.total_items / (waves * 64);
-            // (a launch with fewer than 256 items per wave — the 256x256x16 frame of C1 — takes 128 so that every wave gets some:
-            // 1407 -> 1492 Msamples/s)
-            if (chunk < 256) chunk = (long long)P.total_items < waves * 256 ? 128 : 256;
-            // A wave that claims the last chunk works it off 128 paths at a time while the others have drained: the tail
-            // is chunk / 128 path durations.  4096 cost 2 % on the Cornell frame and 18 % on the glass bunny (long paths);
-            // below ~2048 the curve is flat down to 256, and locality does not suffer (a chunk is still >= 4 pixels).
-            if (chunk > 1024) chunk = 1024;
-            if (c->chunk > 0) chunk = c->chunk;
-            P.chunk = (uint32_t)chunk;
-            HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
-            if (split) {
-                NEXT_EVENT(c->evp, c->evp_used, pa);
-                NEXT_EVENT(c->evp, c->evp_used, pb);
-                HIP_TRY(hipEventRecord(pa, c->stream));
-                if (c->jit_mod) {
-                    long long need = ((long long)P.total_items + 255) / 256, pg = (long long)c->n_cu * 8;
-                    if (int r = rt_jit_launch(c->jit_mod->primary, P, (unsigned)(pg < need ? pg : need), c->stream)) return r;
-                } else
-                    launch_primary(P, c->kind, c->n_cu, c->stream);
-                HIP_TRY(hipEventRecord(pb, c->stream));
-            }
-            NEXT_EVENT(c->ev, c->ev_used, a);
-            NEXT_EVENT(c->ev, c->ev_used, b);
-            HIP_TRY(hipEventRecord(a, c->stream));
-            if (c->jit_mod) {
-                if (int r = rt_jit_launch(c->jit_mod->trace, P, (unsigned)grid, c->stream)) return r;
-            } else
-                launch_trace(P, c->kind, grid, c->stream);
-            HIP_TRY(hipEventRecord(b, c->stream));
-            if (!unstaged) launch_accumulate(P, c->stream);
-            c->sample_base += (uint32_t)K;
-            left -= K;
-        }
+        if (int r = sample_complete_path(c, n)) return r;
     }
     HIP_TRY(hipEventRecord(c->ev_total1, c->stream));
     HIP_TRY(hipGetLastError());
@@ -1370,6 +1451,8 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         c->src_chain = (int)value;
         c->order_valid = false;       // the plan carries the chain set
         c->cost_steps = 0;
+        c->plan_chain_waves = 0;
+        c->plan_rb_pending = false;
     } else if (!strcmp(key, "chain_np_max")) {
         if (value < 0) return fail(RTPBR_EINVAL, "chain_np_max must be >= 0");
         c->chain_np_max = value;

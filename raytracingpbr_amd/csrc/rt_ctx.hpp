@@ -30,7 +30,7 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, int n_cls, int chain_on, hipStream_t st);
+                 int tiny_waves, int n_cu, int n_cls, int chain_on, uint32_t chain_ref_waves, hipStream_t st);
 }  // namespace rt
 
 // run-time compiled per-scene instances (rt_jit.hip)
@@ -157,6 +157,10 @@ struct rtpbr_ctx {
     int src_chain = 1;            // src/ form, fused launches: the plan's chain set runs in the chain kernel beside the pool kernel (rt_chain.hpp)
     long long chain_np_max = 2500000;   // ... frames of more local pixels than this are throughput-bound: no chain set
     int chain_waves = 1024;       // ... the most waves the chain set may take (<= 2048)
+    int plan_chain_waves = 0;     // ... waves of the chain set the LAST plan made (0: not chain-bound / no plan yet), read back asynchronously:
+    uint32_t* plan_rb_host = nullptr;   // page-locked word the copy lands in
+    hipEvent_t ev_plan_rb = nullptr;
+    bool plan_rb_pending = false;
     hipStream_t stream2 = nullptr;      // ... on this stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int src_split = 1;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never (measured at 1080p: one step 0.51 against 0.60 ms fused; two steps 1.3 against 0.65)

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) plan_hist(const uint32_t* __restrict__ co
 // A pixel is heavy when its own chain of march steps is long against BOTH the frame's mean pixel (mean_x16 / 16 times)
 // and a wave's share of the whole frame in march iterations, total / (64 lanes x waves) (bulk_x16 / 16 times).
 __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uint32_t n_waves, uint32_t heavy_own, uint32_t mean_x16, uint32_t bulk_x16,
-                                                 uint32_t tiny_waves, uint32_t n_cls, uint32_t chain_on) {      // chain_on: 0 = no chain set, else the most waves it may take
+                                                 uint32_t tiny_waves, uint32_t n_cls, uint32_t chain_on, uint32_t chain_ref_waves) {      // chain_on: 0 = no chain set, else the most waves it may take; chain_ref_waves: waves of the grid the pool kernel has ALONE
     __shared__ uint32_t h[256];
     const uint32_t b = threadIdx.x;
     h[b] = plan->hist[b];
@@ -235,7 +235,10 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         plan->n_chain = 0;
         plan->n_chain_waves = 0;
         plan->chain_start[0] = 0;
-        if (chain_on && chain > 3.0 * bulk && n_heavy > 0u) {
+        // ("chain-bound" is decided against a wave's share under the grid the pool kernel would have alone: the host makes room for
+        // the chain kernel only AFTER a plan has said so, and the answer must not change because room was made)
+        const double bulk_ref = total / (64.0 * (double)(chain_ref_waves ? chain_ref_waves : (n_waves ? n_waves : 1u)));
+        if (chain_on && chain > 3.0 * bulk_ref && n_heavy > 0u) {
             const double T = chain * 1.15, thr_c = thr > chain / 8.0 ? thr : chain / 8.0;
             const uint32_t max_w = chain_on < 2048u ? chain_on : 2048u;
             // (round 5, after the lean loops lost a third of their instructions: a wave of ONE pixel runs them nearly all the time,
@@ -339,14 +342,14 @@ __global__ void __launch_bounds__(256) plan_scatter(uint32_t* __restrict__ cost,
     }
 }
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, int n_cls, int chain_on, hipStream_t st) {
+                 int tiny_waves, int n_cu, int n_cls, int chain_on, uint32_t chain_ref_waves, hipStream_t st) {
     (void)hipMemsetAsync(plan, 0, offsetof(PlanBuf, age_valid), st);      // (the self-tuned age weights and the lifetimes survive)
     long long need = ((long long)np + 255) / 256, grid = (long long)n_cu * 8;
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(plan_hist, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan);
     hipLaunchKernelGGL(plan_scan, dim3(1), dim3(256), 0, st, plan, np, n_waves, (uint32_t)heavy_own, (uint32_t)mean_x16, (uint32_t)bulk_x16,
-                       (uint32_t)tiny_waves, (uint32_t)n_cls, (uint32_t)chain_on);
+                       (uint32_t)tiny_waves, (uint32_t)n_cls, (uint32_t)chain_on, chain_ref_waves);
     hipLaunchKernelGGL(plan_scatter, dim3((unsigned)grid), dim3(256), 0, st, cost, np, plan, order);
 }
 

@@ -74,33 +74,40 @@ def test_c1_full_frame_l2():
     g.close()
 
 
-@pytest.mark.parametrize("name,tiles", [("c2", None), ("c4", (960, 540, 0, 4)), ("c3", None)])
-def test_whole_frame_l2_against_the_exact_kernels(name, tiles):
+@pytest.mark.parametrize("name,tiles,seeds", [("c2", None, (0, 1, 2)), ("c4", (960, 540, 0, 4), (0,)), ("c3", None, (0,))])
+def test_whole_frame_l2_against_the_exact_kernels(name, tiles, seeds):
     """The result, not a sample of it: the WHOLE frame of C2 and C3, and rank 0's quarter of C4 (its four-rank partition), at
     the config's full resolution and sample count, tolerance flavour against the EXACT HIP kernels — which the same suite
     holds bit-identical to the oracle (test_gpu_fullsize.py, test_gpu_parity.py), so this is the frame the oracle would
     produce in hours.  Display-space per-pixel L2 must meet the north star's bar."""
     wl = workloads.get(name)
     W, H = wl.cfg.width, wl.cfg.height
-    imgs = []
-    for prec in (0, 1):
-        r = hip(wl, prec)
-        if tiles:
-            r.set_tiles(*tiles)
-        r.sample(wl.spp)
-        r.post_process()
-        imgs.append((r.image_pixels, r.image_buffer))
-        assert r.counter("jit_active") == 1
-        r.close()
-    (pe, be), (pf, bf) = imgs
-    own = be[..., 3] > 0
-    assert np.array_equal(own, bf[..., 3] > 0) and np.all(bf[own][:, 3] == wl.spp) and np.all(np.isfinite(pf[own]))
-    d_disp, d_lin = l2(pf[own], pe[own]), l2(bf[own][:, :3] / wl.spp, be[own][:, :3] / wl.spp)
-    worst = float(np.abs(pf[own].astype(np.float64) - pe[own]).max())
-    print(f"[fast] {name} whole frame {W}x{H} x {wl.spp} spp ({int(own.sum())} pixels): display-space L2 vs the exact kernels {d_disp:.3e} "
-          f"(linear {d_lin:.3e}); largest single-pixel difference {worst:.3e}; pixels that differ at all {float(np.mean(np.any(pf[own] != pe[own], axis=-1))):.3f}")
-    assert d_disp < L2_BAR
-    assert d_disp > 0.0
+    # (round 6: the headline config on three seeds — the difference between the flavours is a few thousand flipped samples per
+    # frame, so the figure fluctuates by ~1 / sqrt(flips) from seed to seed; the seed is a launch argument, nothing recompiles)
+    for seed in seeds:
+        imgs = []
+        for prec in (0, 1):
+            r = Renderer(wl.scene, wl.cfg.copy(seed=seed))
+            wl.setup(r)
+            r.set_option("jit", 2)
+            r.set_option("jit_bake", 1)
+            r.set_option("precision", prec)
+            if tiles:
+                r.set_tiles(*tiles)
+            r.sample(wl.spp)
+            r.post_process()
+            imgs.append((r.image_pixels, r.image_buffer))
+            assert r.counter("jit_active") == 1
+            r.close()
+        (pe, be), (pf, bf) = imgs
+        own = be[..., 3] > 0
+        assert np.array_equal(own, bf[..., 3] > 0) and np.all(bf[own][:, 3] == wl.spp) and np.all(np.isfinite(pf[own]))
+        d_disp, d_lin = l2(pf[own], pe[own]), l2(bf[own][:, :3] / wl.spp, be[own][:, :3] / wl.spp)
+        worst = float(np.abs(pf[own].astype(np.float64) - pe[own]).max())
+        print(f"[fast] {name} whole frame {W}x{H} x {wl.spp} spp, seed {seed} ({int(own.sum())} pixels): display-space L2 vs the exact kernels {d_disp:.3e} "
+              f"(linear {d_lin:.3e}); largest single-pixel difference {worst:.3e}; pixels that differ at all {float(np.mean(np.any(pf[own] != pe[own], axis=-1))):.3f}")
+        assert d_disp < L2_BAR, seed
+        assert d_disp > 0.0
 
 
 @pytest.mark.parametrize("name,tile,rank,world", [("c2", 16, 77, 127), ("c3", 16, 37, 127), ("c4", 16, 203, 506), ("c4", 16, 5, 4050)])
@@ -142,6 +149,39 @@ def test_subframe_at_full_sample_count_l2(name, tile, rank, world):
     # the work the two flavours did agrees to a fraction of a percent (decision flips are rare)
     assert abs(cg.raycasts - co.raycasts) <= 2e-3 * co.raycasts and abs(cg.march_steps - co.march_steps) <= 5e-3 * co.march_steps
     g.close()
+
+
+def test_c2_oracle_subsets_hold_the_bar_together():
+    """The north star's bar against the ORACLE itself, not relaxed (round 6; the single 64-tile subset above fluctuates around
+    the frame's value — 0.8 % of a frame holds ~20 of its few thousand flipped samples — and is allowed 2 x the bar): FOUR disjoint
+    sets of 64 tiles of the headline frame at its full 256 spp, 65 536 pixels in all, tolerance flavour against the oracle's
+    frame with the identical random stream: the display-space L2 over their union is below 1e-3, and so is their mean."""
+    wl = workloads.get("c2")
+    W, H = wl.cfg.width, wl.cfg.height
+    tile, world = 16, 127
+    sq_sum, n_px, per = 0.0, 0, []
+    for rank in (11, 45, 77, 110):
+        own = TileLayout(W, H, tile, tile, world).owner_map() == rank
+        g = hip(wl, 1)
+        g.set_tiles(tile, tile, rank, world)
+        g.sample(wl.spp)
+        g.post_process()
+        o = OracleRenderer(wl.scene, wl.cfg)
+        wl.setup(o)
+        o.set_tiles(tile, tile, rank, world)
+        o.sample(wl.spp)
+        o.post_process()
+        d = g.image_pixels[own].astype(np.float64) - o.image_pixels[own]
+        assert np.all(g.image_buffer[own][:, 3] == wl.spp)
+        per.append(float(np.sqrt(np.mean(d * d))))
+        sq_sum += float(np.sum(d * d))
+        n_px += d.size
+        g.close()
+    union = float(np.sqrt(sq_sum / n_px))
+    print(f"[fast] c2 against the oracle on 4 disjoint sets of 64 tiles ({n_px // 3} pixels, {wl.spp} spp): display-space L2 per set "
+          f"{', '.join(f'{x:.3e}' for x in per)}; over their union {union:.3e}; mean {np.mean(per):.3e}")
+    assert union < L2_BAR and float(np.mean(per)) < L2_BAR
+    assert max(per) < 2 * L2_BAR
 
 
 def test_src_form_l2():
