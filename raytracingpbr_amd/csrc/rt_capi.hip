@@ -88,6 +88,8 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     (void)hipFree(c->diff_pixels);
     (void)hipFree(c->objfull);
     (void)hipFree(c->env);
+    (void)hipFree(c->env8);
+    (void)hipFree(c->env_lut);
     (void)hipFree(c->bunny);
     (void)hipFree(c->stage);
     (void)hipFree(c->primary);
@@ -545,9 +547,25 @@ extern "C" int rtpbr_set_env(rtpbr_ctx* c, const void* texels, int w, int h, int
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(c->env);
+    (void)hipFree(c->env8);
+    (void)hipFree(c->env_lut);
     c->env = nullptr;
+    c->env8 = nullptr;
+    c->env_lut = nullptr;
     HIP_TRY(hipMalloc(&c->env, n * sizeof(float4)));
     HIP_TRY(hipMemcpy(c->env, host.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    if (fmt == RTPBR_ENV_RGB8) {
+        // ... and as the reference's image really is (T9): 8-bit texels + the table Image.process() amounts to
+        const uint8_t* s8 = (const uint8_t*)texels;
+        std::vector<uint32_t> packed(n);
+        for (size_t i = 0; i < n; i++) packed[i] = (uint32_t)s8[i * 3] | ((uint32_t)s8[i * 3 + 1] << 8) | ((uint32_t)s8[i * 3 + 2] << 16);
+        float lut[256];
+        for (int i = 0; i < 256; i++) lut[i] = pow_(((float)i / 255.0f) * exposure, gamma);
+        HIP_TRY(hipMalloc(&c->env8, n * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->env_lut, sizeof lut));
+        HIP_TRY(hipMemcpy(c->env8, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->env_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    }
     c->P.env = c->env;
     c->P.env_w = w;
     c->P.env_h = h;
@@ -695,6 +713,8 @@ static void derive_launch(rtpbr_ctx* c, RtJitKey* key, bool* want, bool* strict_
     P.diff_buffer = c->diff_buffer;
     P.diff_pixels = c->diff_pixels;
     P.objfull = c->objfull;
+    P.env8 = (c->env_packed && c->env8) ? c->env8 : nullptr;
+    P.env_lut = c->env_lut;
     P.work_counter = c->work_counter;
     P.counters = c->counters;
     P.wait_lanes = c->wait_lanes;
@@ -1464,6 +1484,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "src_split")) {
         if (value < 0 || value > 256) return fail(RTPBR_EINVAL, "src_split must be 0 (never) .. 256 (bounce-steps per launch up to which the wavefront split runs)");
         c->src_split = (int)value;
+    } else if (!strcmp(key, "env_packed")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "env_packed must be 0 (float4 texels) or 1 (RGBA8 texels + 256-entry table: 8-bit sources, same values)");
+        c->env_packed = (int)value;
     } else if (!strcmp(key, "split_head")) {
         if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "split_head must be -1 (automatic: small frames), 0 (the heavy head fills the first groups) or 1 (interleaved: one head entry per group)");
         c->split_head = (int)value;

@@ -1062,6 +1062,10 @@ RT_D vec3 sky_color(const Params& P, vec3 D) {
         int x = (int)(u * (float)ew), y = (int)(v * (float)eh);
         x = x < 0 ? 0 : (x > ew - 1 ? ew - 1 : x);
         y = y < 0 ? 0 : (y > eh - 1 ? eh - 1 : y);
+        if (P.env8 != nullptr) {       // (wave-uniform) RGBA8 texel + the 256-entry table: bit for bit the float texel
+            const uint32_t w = P.env8[(size_t)x * eh + y];
+            return mk(P.env_lut[w & 255u], P.env_lut[(w >> 8) & 255u], P.env_lut[(w >> 16) & 255u]);
+        }
         float4 t = P.env[(size_t)x * eh + y];
         return mk(t.x, t.y, t.z);
     }

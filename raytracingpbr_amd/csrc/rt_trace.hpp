@@ -101,6 +101,8 @@ RT_D void shade_miss(const Params& P, PathRay& R, uint32_t& n_sky) {
 // so its stores fall into the same few cache lines and merge in L2 before they reach HBM.  A record is the sample's
 // three colour words, 12 bytes (round 3; it was a float4 whose fourth word nobody read: the count a sample adds is 1 by
 // definition and padding pixels of an edge tile are known from the geometry, so they are not written at all).
+// (NOT a non-temporal store: the records of neighbouring samples share 64-byte lines and finish up to a path's lifetime apart —
+// the L2 is what merges them; measured with `nt` stores: WRITE_SIZE of the trace kernel 12.5 -> 15.5 GB per headline step)
 RT_D void write_sample(const Params& P, uint32_t item, vec3 col) {
     reinterpret_cast<StageRec*>(P.stage)[item] = StageRec{col.x, col.y, col.z};
 }
@@ -756,7 +758,17 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                 // the primary record is requested BEFORE the camera ray is regenerated: the ~150 instructions of
                 // start_item cover part of the global-load latency
                 float2 rec = make_float2(0.0f, 0.0f);
-                if (got && P.primary_split) rec = P.primary[R.item];
+                // (read ONCE, streaming: a non-temporal load keeps the 4.3 GB of primary records of a headline step from turning the
+                // L2 over under the staging records, whose partially written lines then live long enough to be completed —
+                // WRITE_SIZE of this kernel 12.49 -> 11.11 GB per step, time unchanged; round 6)
+                if (got && P.primary_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const float* pr = reinterpret_cast<const float*>(P.primary + R.item);
+                    rec = make_float2(__builtin_nontemporal_load(pr), __builtin_nontemporal_load(pr + 1));
+#else
+                    rec = P.primary[R.item];
+#endif
+                }
                 if (got) {
                     int r = start_item(P, R);
                     if (r == 1) {

@@ -206,6 +206,11 @@ struct Params {
     const ObjFull* objfull;
     const float4* env;      // T9 as float4 texels [x][y]
     int32_t env_w, env_h;
+    // T9 as SURVEY.md names it for an 8-bit source (src/ibl.py:14-23: the image is uint8, every channel takes one of 256 values after
+    // Image.process): RGBA8 texels + the 256-entry table of (c / 255 * exposure)^gamma — the same floats, a quarter of the bytes.
+    // nullptr = use `env` (option env_packed, or the map was uploaded as floats)
+    const uint32_t* env8;
+    const float* env_lut;
     const float* bunny;     // 625 weights
     unsigned int* work_counter;
     Counters* counters;

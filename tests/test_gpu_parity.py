@@ -510,6 +510,28 @@ def test_frames_handed_over_without_a_stall_equal_the_synchronous_path():
     b.close()
 
 
+@pytest.mark.parametrize("name", ["tokyo_ibl_env", "src_persistent", "bunny_glass"])
+def test_packed_environment_gives_the_same_bits(name):
+    """option env_packed (round 6): the environment as SURVEY.md T9 names it for the reference's 8-bit image — RGBA8 texels + the
+    256-entry table Image.process() amounts to (src/ibl.py:14-23) — instead of float4 texels: the same floats reach the shading,
+    so image_buffer, ray_buffer and the counters are the oracle's bit for bit, in ahead-of-time and run-time instances."""
+    case = case_by_name(name)
+    o = OracleRenderer(case.scene, case.cfg)
+    case.run(o)
+    for opts in ({"env_packed": 1}, {"env_packed": 1, "jit": 1, "jit_bake": 1}, {"env_packed": 1, "scheduler": 0, "jit": 0}):
+        g = Renderer(case.scene, case.cfg)
+        for k, v in opts.items():
+            g.set_option(k, v)
+        case.run(g)
+        assert np.array_equal(bits(g.image_buffer), bits(o.image_buffer)), opts
+        assert np.array_equal(bits(g.image_pixels), bits(o.image_pixels)), opts
+        if case.cfg.kernel_form == 1:
+            assert np.array_equal(bits(g.ray_buffer), bits(o.ray_buffer)), opts
+        cg, co = g.counters(), o.counters()
+        assert (cg.samples, cg.raycasts, cg.march_steps, cg.hits, cg.sky_lookups) == (co.samples, co.raycasts, co.march_steps, co.hits, co.sky_lookups), opts
+        g.close()
+
+
 def test_refresh_semantics():
     case = case_by_name("src_persistent")
     r = Renderer(case.scene, case.cfg)
