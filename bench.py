@@ -387,7 +387,13 @@ def frame_latency(a, device, W=768, H=432, frames=200):
         r.render()
     r.sync()
     dt_dev = time.perf_counter() - t0
-    tr, _tot, _n = r.last_sample_ms()
+    # device time of the sample kernels (gen + march + shade of one bounce-step), HIP events, mean over 64 frames (a single launch
+    # varies by +-10 %: the launch is as long as its slowest wave)
+    tr = 0.0
+    for _ in range(64):
+        r.render()
+        tr += r.last_sample_ms()[0]
+    tr /= 64.0
     split = bool(r.counter("jit_active"))
     r.close()
     return {"workload": f"src/ pipeline {W}x{H}: Renderer.render() = sample(1) + post_process(), then image_pixels read to the host — "
