@@ -148,9 +148,12 @@ def make_renderer(wl, device, a, jit=True, bake=True):
     return r
 
 
-def measure(wl, r, steps, warmup, fence=None, gather=None, one_step_launches=False):
+def measure(wl, r, steps, warmup, fence=None, gather=None, one_step_launches=False, sync_every_step=True):
     """W warm-up + K timed steps of one workload on an already configured renderer; returns the wall time and the per-launch
-    figures of the kernels (HIP events recorded on the context's own stream by the library)."""
+    figures of the kernels (HIP events recorded on the context's own stream by the library).  sync_every_step = False: the K
+    steps are enqueued back to back and the host waits once, at the end (what a host that does not look at every step does; for
+    sub-millisecond steps — C1 — reading the events after every step costs a fifth of the step); the kernel figures are then
+    those of the LAST step, scaled."""
     form_src = wl.family == "src"
 
     def step():
@@ -170,6 +173,14 @@ def measure(wl, r, steps, warmup, fence=None, gather=None, one_step_launches=Fal
     trace_ms = primary_ms = 0.0
     launches = primary_launches = 0
     t0 = time.perf_counter()
+    if not sync_every_step:
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        tr, _tot, n = r.last_sample_ms()
+        pr, pn = (0.0, 0) if form_src else r.last_primary_ms()
+        return {"dt": dt, "trace_ms": tr * steps, "launches": n * steps, "primary_ms": pr * steps, "primary_launches": pn * steps}
     for _ in range(steps):
         step()
         # HIP-event timing of the kernels; reading it waits for the step, which the timed region must wait for anyway
@@ -232,7 +243,10 @@ def side_config(name, a, device, rank0_of=1):
     r.sample(wl.spp)
     r.sync()
     steps = 20 if name_ == "c1" else 2
-    m = measure(wl, r, steps, 1, one_step_launches=one_step_launches)
+    # (C1 is a 0.5 ms launch: its 20 steps are enqueued back to back, one wait at the end)
+    # (the fused src/ launches settle over three launches: cost plan, then room for the chain kernel once a plan has produced a
+    # chain set, then the age-weighted shares of the new grid)
+    m = measure(wl, r, steps, 3 if (wl.family == "src" and not one_step_launches) else 1, one_step_launches=one_step_launches, sync_every_step=name_ != "c1")
     c, fpu, kernel_s, tflops = roofline_of(wl, r, m, steps, W * H)
     if one_step_launches:       # the counters are those of the LAST launch (one bounce-step per pixel)
         kernel_s = m["trace_ms"] / 1e3 / steps

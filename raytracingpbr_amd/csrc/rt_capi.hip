@@ -856,9 +856,8 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
                 const long long dense = (long long)P.np / (tune::POOL_MIN_PIX_PER_WAVE * tune::WAVES_PER_BLOCK);
                 if (grid > dense) grid = dense;
             }
-            const long long grid_alone = grid < 1 ? 1 : grid;      // the pool kernel's grid when nothing runs beside it
             // The chain kernel (rt_chain.hpp) runs BESIDE the pool kernel and needs wave slots of its own.  Frames up to about
-            // 1080p may be chain-bound (plan_scan decides, on the device, against the grid the pool kernel would have ALONE);
+            // 1080p may be chain-bound (plan_scan decides, on the device, against the grid the pool kernel has beside the chain kernel);
             // when the last plan made a chain set the pool grid makes room — whole multiples of the CU count: an uneven grid
             // costs more than it gives (1024x576 42.8 -> 30 ms, 1280x720 46 -> 40, 1600x900 54.7 -> 50.4, 1080p 58.6 -> 57.3) —
             // and is sized for ~190 pixels per wave.  Larger frames are throughput-bound and keep the whole device for the pool
@@ -867,12 +866,23 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
             const long long chain_blocks = (c->chain_waves + tune::WAVES_PER_BLOCK - 1) / tune::WAVES_PER_BLOCK;
             const bool chain_candidate = c->src_chain != 0 && c->grid_blocks == 0 && c->src_plan && (long long)P.np <= c->chain_np_max;
             const bool chain_room = chain_candidate && (c->plan_chain_waves > 0 || c->src_chain == 2);
-            if (chain_room) {
-                if (grid + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu) grid = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
+            // (the grid WITH room is computed whether or not room is made: it is what the plan decides "chain-bound" against, so that
+            // the decision is the same before and after — the host makes room only once a plan has said so)
+            // Two separate things (round 6 took them apart: `src_chain = 0 / 1 / 2` at 1080p = 56.3 / 56.5 / 53.4 ms showed that what
+            // helps there is the GRID, the plan never finds 1080p chain-bound): (a) a frame that may get a chain set leaves one block
+            // per CU free — four blocks per CU instead of five are faster at these sizes with or without a chain kernel beside them
+            // (1080p 56 -> 53.4 ms); (b) the ~190 pixels per wave of a small frame pay only BESIDE a chain kernel (without one the
+            // heaviest pixels need the larger grid: 768x432 26 against 36 ms) — applied once a plan has produced a chain set.
+            long long grid_room = grid;
+            if (chain_candidate) {
+                if (grid_room + chain_blocks > max_blocks && max_blocks - chain_blocks >= c->n_cu) grid_room = (max_blocks - chain_blocks) / c->n_cu * c->n_cu;
+                if (grid_room < 1) grid_room = 1;
+                grid = grid_room;                                                     // (a)
                 long long want = ((long long)P.np / tune::CHAIN_POOL_PIX_PER_BLOCK + c->n_cu / 2) / c->n_cu * c->n_cu;
                 if (want < (long long)tune::CHAIN_POOL_MIN_BLOCKS_PER_CU * c->n_cu) want = (long long)tune::CHAIN_POOL_MIN_BLOCKS_PER_CU * c->n_cu;
-                if (grid > want) grid = want;
+                if (grid_room > want) grid_room = want;                               // (b): what the plan decides "chain-bound" against
             }
+            if (chain_room) grid = grid_room;
             if (c->grid_blocks > 0) grid = c->grid_blocks;
             if (grid < 1) grid = 1;
             P.total_items = (uint32_t)P.np;
@@ -920,10 +930,10 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
                 }
                 if (c->cost_steps >= c->plan_interval) {
                     // (the plan sizes its heavy waves for THIS launch's grid and decides "chain-bound" against the grid the pool
-                    // kernel has alone: the decision does not depend on whether room has been made already)
+                    // kernel has beside the chain kernel: the decision does not depend on whether room has been made already)
                     launch_plan(c->cost_buffer, c->order, c->plan, (uint32_t)P.np, (uint32_t)grid * 4u, c->heavy_own, c->heavy_mean_x16,
                                 c->heavy_bulk_x16, c->tiny_waves, c->n_cu, (int)((grid + c->n_cu - 1) / c->n_cu), chain_candidate || c->src_chain == 2 ? c->chain_waves : 0,
-                                (uint32_t)grid_alone * 4u, c->stream);
+                                (uint32_t)grid_room * 4u, c->stream);
                     c->order_valid = true;
                     c->cost_steps = 0;
                     if (!c->plan_rb_host) {
@@ -1497,7 +1507,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "src_track must be 0 (never), 1 (one-object bounds only) or 2 (one- and two-object bounds)");
         c->src_track = (int)value;
     } else if (!strcmp(key, "src_op")) {
-        if (value < 0 || value > 3) return fail(RTPBR_EINVAL, "src_op must be 0 .. 3 (bit 0: object-parallel evaluation for sparse waves in the split march and chain kernels, bit 1: in the fused pool kernel)");
+        if (value < 0 || value > 7) return fail(RTPBR_EINVAL, "src_op must be 0 .. 7 (bit 0: object-parallel evaluation for sparse waves in the split march and chain kernels, bit 1: in the fused pool kernel, bit 2: the per-lane lean loop for lanes that track different objects)");
         c->src_op = (int)value;
     } else if (!strcmp(key, "age_weights")) {
         // one hex digit per residency slot, oldest first (0x88888 = equal shares); 0 switches the weighting off

@@ -67,7 +67,7 @@ RT_D void chain_steps_impl(const Params& P, int steps) {
 #ifdef RT_DEBUG_PHASE
         const unsigned long long t_w0 = __builtin_readcyclecounter();
         unsigned long long t_march = 0;
-        unsigned dbg_form[6] = {0, 0, 0, 0, 0, 0}, dbg_steps[6] = {0, 0, 0, 0, 0, 0};
+        unsigned dbg_form[7] = {0, 0, 0, 0, 0, 0, 0}, dbg_steps[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
         for (int s = 0; s < steps; s++) {
             uint32_t key = 0, cnt = 0;

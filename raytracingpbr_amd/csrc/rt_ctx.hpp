@@ -30,7 +30,7 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler);
 void launch_primary(const Params& P, int kind, int n_cu, hipStream_t st);
 void launch_sqrt_exhaustive(unsigned long long* mismatches, hipStream_t st);
 void launch_plan(uint32_t* cost, uint32_t* order, PlanBuf* plan, uint32_t np, uint32_t n_waves, int heavy_own, int mean_x16, int bulk_x16,
-                 int tiny_waves, int n_cu, int n_cls, int chain_on, uint32_t chain_ref_waves, hipStream_t st);
+                 int tiny_waves, int n_cu, int n_cls, int chain_on, uint32_t chain_ref_waves, hipStream_t st);      // chain_ref_waves: waves of the pool grid beside the chain kernel
 }  // namespace rt
 
 // run-time compiled per-scene instances (rt_jit.hip)
@@ -141,7 +141,7 @@ struct rtpbr_ctx {
     int tiny_own = 8;             // pixels per small heavy wave (2 or 4 when the budget allows)
     int leave_x8 = 24;            // a shading pass costs the marching lanes about 3 march iterations
     int src_track = 2;            // tracked-object march steps (heavy waves, sparse phases): 0 off, 1 one-object bounds, 2 also the two-object lean loop
-    int src_op = 3;               // object-parallel nearest() while at most 8 lanes march: bit 0 split march + chain kernel, bit 1 fused pool kernel
+    int src_op = 7;               // sparse-wave evaluations of round 6: bit 0 object-parallel nearest() while at most 8 lanes march (split march + chain kernel), bit 1 the same in the fused pool kernel (builds with RT_POOL_OP), bit 2 the per-lane lean loop
     int heavy_prio = 1;           // heavy waves run at raised issue priority
     int heavy_mean_x16 = 48;      // a pixel is heavy when its cost exceeds 3 x the mean pixel ...
     int heavy_bulk_x16 = 8;       // ... and half a wave's share of the frame (in march iterations)

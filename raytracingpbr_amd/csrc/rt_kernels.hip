@@ -235,8 +235,9 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         plan->n_chain = 0;
         plan->n_chain_waves = 0;
         plan->chain_start[0] = 0;
-        // ("chain-bound" is decided against a wave's share under the grid the pool kernel would have alone: the host makes room for
-        // the chain kernel only AFTER a plan has said so, and the answer must not change because room was made)
+        // ("chain-bound" is decided against a wave's share under the grid the pool kernel has BESIDE the chain kernel — the host
+        // passes it whether or not room has been made yet: it makes room only AFTER a plan has said so, and the answer must not
+        // change because room was made)
         const double bulk_ref = total / (64.0 * (double)(chain_ref_waves ? chain_ref_waves : (n_waves ? n_waves : 1u)));
         if (chain_on && chain > 3.0 * bulk_ref && n_heavy > 0u) {
             const double T = chain * 1.15, thr_c = thr > chain / 8.0 ? thr : chain / 8.0;
@@ -279,8 +280,10 @@ __global__ void __launch_bounds__(256) plan_scan(PlanBuf* plan, uint32_t np, uin
         // wave; the weights that make them end together are close to 1 / lifetime after ONE measurement and settle in two or
         // three.  Weights are 6-bit integers around 16 (entries of `order` per round), at most 4 : 1 apart.
         if (n_cls >= 2u && n_cls <= 8u) {
-            if (!plan->age_valid || plan->age_cls != n_cls)
+            if (!plan->age_valid)
                 for (uint32_t c = 0; c < 8u; c++) plan->age_wf[c] = 16.0f;
+            else if (plan->age_cls != n_cls)      // the grid changed (room made for the chain kernel): keep the tuned weights of the
+                for (uint32_t c = plan->age_cls; c < 8u; c++) plan->age_wf[c] = plan->age_wf[plan->age_cls ? plan->age_cls - 1u : 0u];      // classes that remain, the last one's for new ones
             double tot = 0.0, cnt = 0.0;
             bool have = true;
             for (uint32_t c = 0; c < n_cls; c++) {

@@ -504,6 +504,41 @@ RT_D int march_fast_src(const Params& P, Lane& L, Trk& lb, int k, int max_it, in
     return it;
 }
 
+// The lean loop for lanes that track DIFFERENT objects (round 6): every marching lane holds a valid bound for its own nearest
+// object.  Each lane gathers ITS object's constants from the block's LDS table once (16 registers) and the loop evaluates that one
+// object per lane — general rotation, per-lane shape switch: the object-parallel evaluation's arithmetic, i.e. bit for bit the
+// |sdf_k|(p) of the unrolled code — with the bound test, the raycast bookkeeping and one vote per step: ~100 instructions for ANY
+// number of rays on ANY objects, where the tracked rounds cost one round per distinct object (1.7 kcycles measured), the
+// object-parallel step 2.0 k and the unrolled full evaluation 2.7 k.  The rays that make a launch long graze one surface each for
+// hundreds of steps — different surfaces in the same wave: this is their loop.  Ends like the one-object loop: a lane fails its
+// bound (it then waits for the wave's next full / object-parallel evaluation), a raycast ends, or max_it steps were taken.
+template <int KIND, bool TWO>
+RT_D int march_fast_src_lanes(const Params& P, const ObjFull* lds_obj, Lane& L, Trk& T, int max_it) {
+    float& lb = T.lb2;
+    const bool marching = L.state == ST_MARCH;
+    const unsigned long long mm = __ballot(marching);
+    const ObjM ob = *reinterpret_cast<const ObjM*>(lds_obj + (marching ? L.idx : 0));
+    const float eps = track_eps_loop(P, L.o, lb);
+    int it = 0;
+    unsigned long long fail = 0ull;
+    for (;;) {
+        const float dk = fabs_(signed_distance<KIND>(P, ob, L.o));
+        const bool ok = marching & (lb > dk + eps) & (!P.cfg.nearest_init | (dk < P.cfg.max_dis));
+        const unsigned long long okm = mm & __builtin_amdgcn_ballot_w64(lb > dk + eps) & (P.cfg.nearest_init ? __builtin_amdgcn_ballot_w64(dk < P.cfg.max_dis) : ~0ull);
+        fail = mm & ~okm;
+        if (ok) {
+            const float s_new = march_update_src_lean<false, false>(P, L, L.idx, dk);
+            lb = track_decay(lb, s_new, eps);
+            if constexpr (TWO) T.lb3 = track_decay(T.lb3, s_new, eps);
+        }
+        it++;
+        const unsigned long long live = okm & __builtin_amdgcn_ballot_w64(L.state == ST_MARCH);
+        if ((live != mm) | (max_it > 0 && it >= max_it)) break;
+    }
+    if ((fail >> (threadIdx.x & 63u)) & 1ull) lb = -1.0f;
+    return it;
+}
+
 // The lean loop on TWO objects: every marching lane tracks the same pair {a, b}, a < b, and holds a valid lb3.  Both objects
 // are evaluated, the nearer one (the lower index on a tie, as nearest() resolves it: objects are visited in index order with a
 // strict `<`) is exactly what nearest() returns while lb3 > min + eps.  lb2 is re-derived on the way (the other object of the
@@ -576,7 +611,8 @@ RT_D int march_fast2_src(const Params& P, Lane& L, Trk& T, int a, int b, int max
 //   3  lanes with a valid lb2 take one tracked step each on their own object — unless too many would have to wait;
 //   4  a full evaluation for everybody (three smallest distances: both bounds fresh);
 //   5  (callers that pass an OpView; at most 8 lanes marching, at most 8 objects, option src_op) the object-parallel evaluation
-//      in place of 3 and 4.
+//      in place of 3 and 4;
+//   6  (same callers, src_op bit 2) every lane's lb2 promises to hold but the lanes track different objects: the per-lane lean loop.
 // "Promises": lb > the lane's LAST distance — a predictor only (the loops test exactly); it keeps a wedge ray from paying
 // for a one-object attempt that fails on its first step after every full evaluation.  Returns the form taken; `steps` =
 // iterations of a lean loop (1 otherwise).
@@ -603,6 +639,11 @@ RT_D int tracked_iteration(const Params& P, Lane& L, Trk& T, int n_march, int ma
             if (TWO && (RT_TRK_W1 != 0) && w1) steps = march_fast_src<KIND, NOBJ, SIG, TWO, (TWO && RT_TRK_W1 != 0)>(P, L, T, k0, max_it, why);
             else steps = march_fast_src<KIND, NOBJ, SIG, TWO>(P, L, T, k0, max_it, why);
             return 1;
+        }
+        // every lane's bound promises to hold, but they track different objects: the per-lane lean loop (form 6, round 6)
+        if (V.xch != nullptr && (P.src_op & 4) != 0) {
+            steps = march_fast_src_lanes<KIND, TWO>(P, V.lds_obj, L, T, max_it);
+            return 6;
         }
     }
     if constexpr (TWO) if (two && __ballot(marching & (T.lb3 > L.dist) & (T.k2 != L.idx)) == mm) {

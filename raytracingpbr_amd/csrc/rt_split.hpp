@@ -144,8 +144,8 @@ RT_D void src_march_impl(const Params& P) {
     const unsigned long long t_wave0 = __builtin_readcyclecounter();
     unsigned dbg_iters = 0, dbg_iters_seq = 0, dbg_fast_calls = 0, dbg_fast_steps = 0, dbg_fast2_calls = 0, dbg_fast2_steps = 0, dbg_full2 = 0, dbg_trk = 0, dbg_plain = 0, dbg_tail_lanesteps = 0, dbg_op = 0;
     unsigned long long t_seq_done = 0;
-    unsigned long long t_form[6] = {0, 0, 0, 0, 0, 0};      // tail only: cycles inside the march step by form (0 = plain steps, 1..5 = tracked_iteration's forms)
-    unsigned n_form[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_form[7] = {0, 0, 0, 0, 0, 0, 0};      // tail only: cycles inside the march step by form (0 = plain steps, 1..5 = tracked_iteration's forms)
+    unsigned n_form[7] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t a_item = 0;
     const uint32_t h = (blockIdx.x * 4u + (threadIdx.x >> 6));
 #endif
@@ -338,7 +338,7 @@ RT_D void src_march_impl(const Params& P) {
                     if (form == 1) { dbg_fast_calls++; dbg_fast_steps += (unsigned)it; }
                     else if (form == 2) { dbg_fast2_calls++; dbg_fast2_steps += (unsigned)it; }
                     else if (form == 3) dbg_trk++;
-                    else if (form == 5) dbg_op++;
+                    else if (form == 5 || form == 6) dbg_op++;
                     else dbg_full2++;
                     if (t_seq_done) dbg_tail_lanesteps += wave_sum(L.n_steps - steps_before);
                     dbg_iters++;
@@ -366,7 +366,7 @@ RT_D void src_march_impl(const Params& P) {
 #ifdef RT_DEBUG_PHASE
     if (lane == 0) {   // per-wave timeline, written over diff_buffer (unused without adaptive sampling; the host reads it back)
         unsigned long long* w = reinterpret_cast<unsigned long long*>(P.diff_buffer) + (size_t)h * 16u;
-        for (int f = 0; f < 6; f++) w[8 + f] = t_form[f] | ((unsigned long long)n_form[f] << 40);      // tail: cycles | calls << 40, by form
+        for (int f = 0; f < 7; f++) w[8 + f] = t_form[f] | ((unsigned long long)n_form[f] << 40);      // tail: cycles | calls << 40, by form
         w[0] = t_wave0;
         w[1] = t_seq_done;
         w[2] = __builtin_readcyclecounter();

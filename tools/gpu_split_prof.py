@@ -43,8 +43,8 @@ tot = lambda a: int(a.sum())
 print(json.dumps({"all_waves": {"iterations": tot(it), "bulk_iterations": tot(its), "lean1_calls": tot(db[:, 4] & 0xffffffff), "lean1_steps": tot(db[:, 4] >> 32), "lean2_calls": tot(db[:, 7] & 0xffffffff),
                                 "lean2_steps": tot(db[:, 7] >> 32), "full": tot(db[:, 5] & 0xffff), "op": tot((db[:, 5] >> 16) & 0xffff), "tracked": tot(db[:, 5] >> 32), "plain": tot(db[:, 6] & 0xffffffff),
                                 "tail_lanesteps": tot(db[:, 6] >> 32), "tail_kcycles_mean": round(float((end - seq).mean()), 1), "bulk_kcycles_mean": round(float((seq - start).mean()), 1)}}))
-fc = db[:, 8:14] & ((1 << 40) - 1); fn = db[:, 8:14] >> 40
-print(json.dumps({"tail_by_form(plain,lean1,lean2,tracked,full,op)": {"calls": [int(x) for x in fn.sum(axis=0)], "Mcycles": [round(float(x) / 1e6, 2) for x in fc.sum(axis=0)],
+fc = db[:, 8:15] & ((1 << 40) - 1); fn = db[:, 8:15] >> 40
+print(json.dumps({"tail_by_form(plain,lean1,lean2,tracked,full,op,lanes)": {"calls": [int(x) for x in fn.sum(axis=0)], "Mcycles": [round(float(x) / 1e6, 2) for x in fc.sum(axis=0)],
                                                                       "kcycles_per_call": [round(float(c) / max(1, int(n)) / 1e3, 3) for c, n in zip(fc.sum(axis=0), fn.sum(axis=0))]},
                   "tail_Mcycles_total": round(float((end - seq).sum()) / 1e3, 2)}))
 r.close()

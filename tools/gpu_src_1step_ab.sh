@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: A/B of option sets on one-step launches (and optionally fused ones):  bash tools/gpu_r6_ab.sh <tag> "<K=V ...>" "<K=V ...>" ...   ("-" = defaults)
+# round 6: A/B of option sets on one-step launches (and optionally fused ones):  bash tools/gpu_src_1step_ab.sh <tag> "<K=V ...>" "<K=V ...>" ...   ("-" = defaults)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=${1:-r06_ab}; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6: HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the headline step's kernels for option sets:
-#   bash tools/gpu_r6_traffic.sh <tag> "<bench options A>" "<bench options B>" ...     ("-" = none)      COUNTERS="WRITE_SIZE FETCH_SIZE"
+#   bash tools/gpu_traffic_ab.sh <tag> "<bench options A>" "<bench options B>" ...     ("-" = none)      COUNTERS="WRITE_SIZE FETCH_SIZE"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=${1:-r06_traffic}; shift
