@@ -376,9 +376,13 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * "src_op" (round 6: bit 0 = while at most 8 lanes of a wave march — the tail of a one-step launch, a chain wave of a few pixels —
  * the wave evaluates nearest() OBJECT-PARALLEL: lane (r, j) evaluates object j for the r-th marching ray from the LDS table and a DPP
  * butterfly over each group of eight lanes returns nearest / second / third, bit-identical; split march and chain kernels; bit 1 =
- * the fused pool kernel too, only in builds with -DRT_POOL_OP=1: it spills there; default 3), "split_head" (split march kernel: the
+ * the fused pool kernel too, only in builds with -DRT_POOL_OP=1: it spills there; bit 2 = the per-lane lean loop: when every marching
+ * lane holds a valid bound but for a DIFFERENT object, each lane evaluates its own object from the LDS table in one loop; default 7),
+ * "split_head" (split march kernel: the
  * cost-ordered list's heavy head interleaved over the groups, one entry per group, instead of filling the first groups: -1 = for
  * frames of at most 600 000 pixels (default), 0 never, 1 always),
+ * "env_packed" (1, default: an environment uploaded as 8-bit texels is read as RGBA8 texels + the 256-entry table of
+ * (c / 255 * exposure)^gamma — the same floats, a quarter of the bytes, same speed; 0 = float4 texels),
  * "src_track" (same kernel: 1 = tracked-object march steps — a lane that knows a lower bound of every object but the
  * nearest one evaluates only that one, exactly; heavy waves always use them), "sparse_lanes" (... other waves while at
  * most this many lanes march, 0 = never; default 24), "leave_x8" (cost of a shading pass in eighths of a march iteration:
