@@ -37,6 +37,18 @@ for seed in range(lo, hi):
                      {"src_split": 256, "src_track": 1, "split_wait": 40, "jit": 1},
                      {"src_split": 0, "src_chain": 2, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "chain_waves": 64, "jit": 1, "jit_bake": seed % 2},
                      {"src_split": 0, "src_chain": 2, "plan_interval": 2, "chain_waves": 3, "grid_blocks": 2, "residency": 4, "jit": 0}]
+    if os.environ.get("ONLY_R6") == "1" and cfg.kernel_form == 1:
+        # round 6: the object-parallel evaluation and the per-lane lean loop of sparse waves (src_op bits 0 / 2), the interleaved heavy
+        # head, the packed environment — in the split march and the chain kernel, on grids where nearly every iteration is sparse
+        j = 1 if seed % 16 == 1 else 0      # (a run-time instance costs ~7 s per scene: every fourth src/ scene)
+        variants = [{"src_split": 256, "src_op": 7, "split_head": 1, "plan_interval": 1, "jit": j, "jit_bake": j},
+                    {"src_split": 256, "src_op": 7, "split_head": 1, "grid_blocks": 1, "split_wait": 1, "sparse_lanes": 64, "jit": 0},
+                    {"src_split": 256, "src_op": 3, "split_head": 0, "grid_blocks": 2, "split_wait": 3, "jit": 0},
+                    {"src_split": 256, "src_op": 5, "plan_interval": 2, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "sparse_lanes": 64, "jit": 0, "env_packed": 0},
+                    {"src_split": 256, "src_op": 0, "split_head": 1, "jit": 0},
+                    {"src_split": 0, "src_chain": 2, "src_op": 7, "plan_interval": 1, "heavy_mean_x16": 0, "heavy_bulk_x16": 0, "chain_waves": 64, "jit": j},
+                    {"src_split": 0, "src_chain": 2, "src_op": 7, "plan_interval": 2, "chain_waves": 3, "grid_blocks": 2, "residency": 4, "jit": 0},
+                    {"src_split": 1, "src_chain": 1, "jit": 0}]
     for opts in variants:
         g = Renderer(sc, cfg)
         for k, v in opts.items(): g.set_option(k, v)
