@@ -320,9 +320,11 @@ RT_D void march_step_src_full3(const Params& P, Lane& L, Trk& T) {
 // row_half_mirror: no LDS, no permute unit) yields the smallest distance, the LOWEST index that attains it (nearest() visits
 // the objects in index order with a strict `<`: src/scene.py:48-54), and — the same again with the winner masked out — the
 // second and third smallest with the second's index: everything nearest_exact3 returns.  The group's first lane writes the four
-// words back to the exchange buffer, the ray's home lane reads them.  ~140 instructions whatever the scene's shapes are
-// (the shape switch serialises the types present: sphere + box + cylinder ~ 80), independent of the number of marching rays.
-// Bit-identical by construction: the same |sdf_j|(p) per object, the same winner, valid bounds.
+// words back to the exchange buffer, the ray's home lane reads them.  ~200 instructions for the seven-object scene (the shape
+// switch serialises the types present: sphere + box + cylinder ~ 80; five reductions of three DPP steps), independent of the
+// number of marching rays; measured in the tails of one-step launches (instrumented build): 2.04 kcycles per call against 2.67 for
+// the unrolled three-smallest evaluation and 1.73 for the tracked rounds it replaces (two LDS round trips and the dependent DPP
+// chain are a third of it).  Bit-identical by construction: the same |sdf_j|(p) per object, the same winner, valid bounds.
 struct OpView {
     const ObjFull* lds_obj;     // the block's object table (stage_objects)
     float4* xch;                // 8 entries of this wave: ray positions in, results out
