@@ -281,7 +281,7 @@ int rtpbr_sample(rtpbr_ctx* ctx, int n);
 /* post_process() src/postprocessor.py:24-43: image_buffer -> image_pixels. */
 int rtpbr_post_process(rtpbr_ctx* ctx);
 
-/* Block until everything enqueued on the context's stream has finished. */
+/* Block until everything enqueued on the context has finished (its stream, and the copies of rtpbr_read_buffer_async). */
 int rtpbr_sync(rtpbr_ctx* ctx);
 
 /* field.to_numpy() / from_numpy(): copy a whole buffer to/from host memory (blocking). */
