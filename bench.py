@@ -275,7 +275,7 @@ def side_config(name, a, device, rank0_of=1):
             out["hbm_fast"] = {"hbm_bytes_per_step": tj["fast"]["hbm_bytes_per_step"], "times_algorithmic": tj["fast"]["times_algorithmic"],
                                "exact_kernels_hbm_bytes_per_step": tj["exact"]["hbm_bytes_per_step"], "exact_times_algorithmic": tj["exact"]["times_algorithmic"],
                                "kind": "a COMMITTED constant from profiles/hbm_traffic_fast.json (separate FETCH_SIZE / WRITE_SIZE passes), not a measurement of this run",
-                               "note": "no staging in this flavour (LDS accumulators + f32 atomics); what remains is the primary records, 8 B per sample written and read"}
+                               "note": "no staging in this flavour (LDS accumulators + f32 atomics); what remains is the primary records, 5 B per sample written and read"}
         except Exception:
             pass
     if name == "c3_valu":
@@ -584,7 +584,7 @@ def main():
             impl_bytes = int(80 * W * H * max(1, SPP // res) + 32 * c.deposits + 16 * c.sky_lookups)
         else:
             split_on = m["primary_launches"] > 0
-            impl_bytes = int((24 + (16 if split_on else 0)) * c.samples + 32 * W * H * (launches / a.steps) + 16 * c.sky_lookups)
+            impl_bytes = int((24 + (10 if split_on else 0)) * c.samples + 32 * W * H * (launches / a.steps) + 16 * c.sky_lookups)
         jit_on = bool(r.counter("jit_active"))
         if wl.family == "src":
             kname, pname = ("rt_jit_persistent_pool" if jit_on else "persistent_pool"), None
@@ -628,7 +628,7 @@ def main():
                     "traffic": traffic, "kernel": kname,
                     "traffic_kind": "a COMMITTED constant from the PMC passes of profiles/hbm_traffic.json (rocprofv3 cannot run inside this process), not a measurement of this run" if traffic else None,
                     # what THIS run moved by construction, from its own counts (per step, all kernels): the complete-path form stages
-                    # 12 B per sample (pool kernel W, accumulate R) and 8 B of primary record per sample (primary kernel W, pool
+                    # 12 B per sample (pool kernel W, accumulate R) and 5 B of primary record per sample (primary kernel W, pool
                     # kernel R) and read-modify-writes T7 once per pixel and launch; the src/ form moves T6 (40 B R + W) per pixel
                     # and residency, T7 (16 B R + W) per deposit and 16 B per sky lookup
                     "implementation_kind": "a MODEL from this run's own counts (records x bytes), not a counter measurement; the src/ form's figure assumes "
@@ -638,8 +638,8 @@ def main():
         }
         if wl.family != "src":
             split = m["primary_launches"] > 0
-            out["staging"] = {"bytes_per_step": int((12 + (8 if split else 0)) * c.samples),
-                              "note": "transient device memory of one step: one 12-byte colour record per pixel-sample (+ one float2 primary record), "
+            out["staging"] = {"bytes_per_step": int((12 + (5 if split else 0)) * c.samples),
+                              "note": "transient device memory of one step: one 12-byte colour record per pixel-sample (+ one 5-byte primary record), "
                                       "reduced in sample order into image_buffer; reserved before the timed region (option reserve_spp)"}
         if multi:
             out["multi_gpu"] = multi

@@ -639,11 +639,12 @@ extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
 
 static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj, P.box_sig, P.objm); }
 
-// Staging (one 12-byte StageRec per item) and, for the primary split, the primary records (one float2 per item).
+// Staging (one 12-byte StageRec per item) and, for the primary split, the primary records (5 bytes per item: a float, then a byte).
 // Grown on demand; hipMalloc of several GB takes 50..700 ms, so callers that time whole frames can
 // reserve up front (option "reserve_spp").
 // Returns RTPBR_ENOMEM (nothing allocated, no sticky HIP error) when the device has no room: the caller then renders
 // with fewer samples per launch instead of failing.
+constexpr size_t PRIMARY_REC_BYTES = 5;     // float t_eval + one byte of idx | state
 static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
     if (need <= *cap) return RTPBR_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -664,7 +665,7 @@ static int ensure_staging(rtpbr_ctx* c, size_t items, bool split, bool stage = t
     if (stage)
         if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(StageRec))) return r;
     if (split)
-        if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * sizeof(float2))) return r;
+        if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * PRIMARY_REC_BYTES)) return r;
     return RTPBR_OK;
 }
 
@@ -1066,7 +1067,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
         const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
         // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
         const bool unstaged = c->precision != 0 && c->jit_mod != nullptr && P.scheduler == 1;
-        long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
+        long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? PRIMARY_REC_BYTES : 0));
         if (per_spp < 1) per_spp = 1;
         long long kmax = c->staging_bytes / per_spp;
         if (kmax < 1) kmax = 1;
@@ -1084,6 +1085,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
             continue;
         }
         P.primary = c->primary;
+        P.primary_code = reinterpret_cast<uint8_t*>(c->primary + (size_t)P.np * (size_t)K);
         P.primary_split = split ? 1 : 0;
         P.primary_lean = c->primary_lean;
         P.drain_lanes = c->drain_lanes;
@@ -1611,7 +1613,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (int r = set_dev(c)) return r;
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
         const bool unstaged = c->precision != 0 && c->scheduler != 0;      // the tolerance flavour has no staging (rtpbr_sample)
-        long long per_spp = (long long)c->P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? sizeof(float2) : 0));
+        long long per_spp = (long long)c->P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? PRIMARY_REC_BYTES : 0));
         if (per_spp < 1) per_spp = 1;
         long long kmax = c->staging_bytes / per_spp;
         long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)c->P.np;

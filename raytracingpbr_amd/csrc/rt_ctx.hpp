@@ -106,7 +106,7 @@ struct rtpbr_ctx {
     float* bunny = nullptr;
     float* stage = nullptr;          // 12 bytes per pixel-sample of a launch (rt::StageRec)
     size_t stage_cap = 0;  // bytes
-    float2* primary = nullptr;
+    float* primary = nullptr;   // primary records: items floats (t_eval), then items bytes (idx | state << 5)
     size_t primary_cap = 0;
     int drain_lanes = 16;    // complete-path pool kernel: culled wave march for the drain (<= this many lanes marching, work exhausted)
     int primary_lean = 1;    // one-object lean loop in the primary kernel

@@ -465,8 +465,8 @@ RT_D void primary_rays_impl(const Params& P) {
             }
         }
         if (item < P.total_items) {
-            uint32_t code = (uint32_t)L.idx | ((uint32_t)(valid ? L.state : ST_IDLE) << 8);
-            P.primary[item] = make_float2(L.t_eval, __builtin_bit_cast(float, code));
+            P.primary[item] = L.t_eval;
+            P.primary_code[item] = (uint8_t)((uint32_t)L.idx | ((uint32_t)(valid ? L.state : ST_IDLE) << 5));
         }
         n_steps += L.n_steps;
         n_raycasts += L.n_raycasts;
@@ -757,26 +757,27 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                 bool roulette0 = false;
                 // the primary record is requested BEFORE the camera ray is regenerated: the ~150 instructions of
                 // start_item cover part of the global-load latency
-                float2 rec = make_float2(0.0f, 0.0f);
+                float rec_t = 0.0f;
+                uint32_t rec_code = 0;
                 // (read ONCE, streaming: a non-temporal load keeps the 4.3 GB of primary records of a headline step from turning the
                 // L2 over under the staging records, whose partially written lines then live long enough to be completed —
                 // WRITE_SIZE of this kernel 12.49 -> 11.11 GB per step, time unchanged; round 6)
                 if (got && P.primary_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                    const float* pr = reinterpret_cast<const float*>(P.primary + R.item);
-                    rec = make_float2(__builtin_nontemporal_load(pr), __builtin_nontemporal_load(pr + 1));
+                    rec_t = __builtin_nontemporal_load(P.primary + R.item);
+                    rec_code = __builtin_nontemporal_load(P.primary_code + R.item);
 #else
-                    rec = P.primary[R.item];
+                    rec_t = P.primary[R.item];
+                    rec_code = P.primary_code[R.item];
 #endif
                 }
                 if (got) {
                     int r = start_item(P, R);
                     if (r == 1) {
                         if (P.primary_split) {
-                            const uint32_t code = __builtin_bit_cast(uint32_t, rec.y);
-                            R.t_eval = rec.x;
-                            R.idx = (int)(code & 0xffu);
-                            resumed = code >> 8;                 // ST_HIT or ST_MISS
+                            R.t_eval = rec_t;
+                            R.idx = (int)(rec_code & 31u);
+                            resumed = rec_code >> 5;             // ST_HIT or ST_MISS
                         } else {
                             alive = true;
                         }

@@ -187,7 +187,8 @@ struct Params {
     int32_t mlp_full;       // bunny: compute both 32-slot halves when at least this many wait, else the first 32
     // pointers
     float* stage;           // 3 floats per work item (StageRec)
-    float2* primary;        // per item: {t_eval, bits(idx | state << 8)} written by primary_rays, read by the pool kernel
+    float* primary;         // per item: t_eval of the primary raycast, written by primary_rays, read by the pool kernel
+    uint8_t* primary_code;  // per item: idx | state << 5 (32 objects, 5 states) — 5 bytes per item in all, not a float2 (round 6)
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
     int32_t drain_lanes;    // pool kernel, work exhausted: at most this many marching lanes go on in the culled wave march (0 = never)
     int32_t primary_lean;   // ... whose march goes on in a one-object loop while the whole wave needs one object only (primary_lean_obj)
