@@ -645,6 +645,10 @@ static void pack_objects(rtpbr_ctx* c, Params& P) { pack_table(c->objm, c->n_obj
 // Returns RTPBR_ENOMEM (nothing allocated, no sticky HIP error) when the device has no room: the caller then renders
 // with fewer samples per launch instead of failing.
 constexpr size_t PRIMARY_REC_BYTES = 5;     // float t_eval + one byte of idx | state
+// staging of `items` samples: the 12-byte records, then (dense staging) one fill count per chunk of >= 32 items and one byte per record
+constexpr size_t STAGE_ITEM_BYTES = 14;     // what a sample is budgeted at (12 + 1 + 4 / 32, rounded up)
+constexpr uint32_t DENSE_CHUNK_MIN = 32, DENSE_CHUNK_MAX = 256, DENSE_BATCH_MAX = 4096;
+static size_t stage_bytes(size_t items) { return items * sizeof(StageRec) + (items / DENSE_CHUNK_MIN + 2) * sizeof(uint32_t) + items; }
 static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
     if (need <= *cap) return RTPBR_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -663,7 +667,7 @@ static int staging_alloc(rtpbr_ctx* c, void** ptr, size_t* cap, size_t need) {
 }
 static int ensure_staging(rtpbr_ctx* c, size_t items, bool split, bool stage = true) {
     if (stage)
-        if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, items * sizeof(StageRec))) return r;
+        if (int r = staging_alloc(c, (void**)&c->stage, &c->stage_cap, stage_bytes(items))) return r;
     if (split)
         if (int r = staging_alloc(c, (void**)&c->primary, &c->primary_cap, items * PRIMARY_REC_BYTES)) return r;
     return RTPBR_OK;
@@ -1067,7 +1071,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
         const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
         // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
         const bool unstaged = c->precision != 0 && c->jit_mod != nullptr && P.scheduler == 1;
-        long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? PRIMARY_REC_BYTES : 0));
+        long long per_spp = (long long)P.np * (long long)((unstaged ? 0 : STAGE_ITEM_BYTES) + (split_ok ? PRIMARY_REC_BYTES : 0));
         if (per_spp < 1) per_spp = 1;
         long long kmax = c->staging_bytes / per_spp;
         if (kmax < 1) kmax = 1;
@@ -1100,6 +1104,28 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
         if (chunk > tune::CHUNK_MAX) chunk = tune::CHUNK_MAX;
         if (c->chunk > 0) chunk = c->chunk;
         P.chunk = (uint32_t)chunk;
+        // dense staging (rt_trace.hpp stage_sample, accumulate_dense): the claim must be whole pixels or a whole fraction of one, and
+        // fit the record's one-byte offset; a launch that has no such claim size near the one wanted keeps the item-linear records
+        P.stage_dense = 0;
+        if (c->stage_dense && !unstaged && P.scheduler == 1) {
+            long long lo = DENSE_CHUNK_MIN, hi = chunk < 64 ? 64 : chunk > (long long)DENSE_CHUNK_MAX ? (long long)DENSE_CHUNK_MAX : chunk, cc = 0;
+            if (c->chunk > 0) lo = hi = c->chunk;       // a claim size that was asked for is kept as it is (or the records stay item-linear)
+            if (lo >= (long long)DENSE_CHUNK_MIN && hi <= (long long)DENSE_CHUNK_MAX)
+                for (long long t = hi; t >= lo; t--)
+                    if (t % K == 0 || K % t == 0) { cc = t; break; }
+            const long long unit = cc > K ? cc : K;      // one divides the other: their least common multiple
+            if (cc > 0 && unit <= (long long)DENSE_BATCH_MAX) {
+                P.chunk = (uint32_t)cc;
+                P.stage_dense = 1;
+                P.acc_batch = (uint32_t)(unit * ((long long)DENSE_BATCH_MAX / unit));
+                P.acc_magic_k = K > 1 ? (uint32_t)(0x100000000ULL / (unsigned long long)K) + 1u : 0u;
+                P.acc_magic_chunk = (uint32_t)(0x100000000ULL / (unsigned long long)cc) + 1u;
+                const size_t n_fill = (size_t)P.total_items / (size_t)cc + 1;
+                P.stage_fill = reinterpret_cast<uint32_t*>(c->stage + (size_t)P.total_items * 3u);
+                P.stage_idx = reinterpret_cast<uint8_t*>(P.stage_fill + n_fill);
+                HIP_TRY(hipMemsetAsync(P.stage_fill, 0, n_fill * sizeof(uint32_t), c->stream));
+            }
+        }
         HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
         if (split) {
             NEXT_EVENT(c->evp, c->evp_used, pa);
@@ -1120,7 +1146,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
         } else
             launch_trace(P, c->kind, grid, c->stream);
         HIP_TRY(hipEventRecord(b, c->stream));
-        if (!unstaged) launch_accumulate(P, c->stream);
+        if (!unstaged) launch_accumulate(P, c->n_cu, c->stream);
         c->sample_base += (uint32_t)K;
         left -= K;
     }
@@ -1562,6 +1588,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "refill_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "refill_lanes must be 1..64");
         c->refill_lanes = (int)value;
+    } else if (!strcmp(key, "stage_dense")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "stage_dense must be 0 (item-linear staging) or 1 (records appended per claim in completion order)");
+        c->stage_dense = (int)value;
     } else if (!strcmp(key, "primary_split")) {
         if (value < 0 || value > 2) return fail(RTPBR_EINVAL, "primary_split must be 0 (never), 1 (large launches) or 2 (always)");
         c->primary_split = (int)value;
@@ -1613,7 +1642,7 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
         if (int r = set_dev(c)) return r;
         const bool split_ok = c->primary_split && c->scheduler != 0 && !(c->have_scene && (c->kind == KIND_BUNNY || c->kind == KIND_MIXED));
         const bool unstaged = c->precision != 0 && c->scheduler != 0;      // the tolerance flavour has no staging (rtpbr_sample)
-        long long per_spp = (long long)c->P.np * (long long)((unstaged ? 0 : sizeof(StageRec)) + (split_ok ? PRIMARY_REC_BYTES : 0));
+        long long per_spp = (long long)c->P.np * (long long)((unstaged ? 0 : STAGE_ITEM_BYTES) + (split_ok ? PRIMARY_REC_BYTES : 0));
         if (per_spp < 1) per_spp = 1;
         long long kmax = c->staging_bytes / per_spp;
         long long k32 = (0xFFFFFFFFLL - work_margin(c)) / (long long)c->P.np;

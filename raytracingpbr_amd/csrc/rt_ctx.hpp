@@ -12,7 +12,7 @@
 
 namespace rt {
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
-void launch_accumulate(const Params& P, hipStream_t st);
+void launch_accumulate(const Params& P, int n_cu, hipStream_t st);
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
 void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
 int persistent_pool_blocks_per_cu(int kind);
@@ -129,6 +129,10 @@ struct rtpbr_ctx {
     int ready_low = 4;
     int jit_waves = 0;            // waves per SIMD the run-time pool kernel is compiled for (0 = as the ahead-of-time instances)
     int chunk = 0;                // work items claimed per atomic by the pool kernels (0 = automatic)
+    // complete-path pool kernel: 1 = records appended per claim in completion order (rt_trace.hpp stage_sample).  Measured on the headline
+    // step (round 6): trace-kernel WRITE 11.06 -> 8.75 GB, but trace 96.3 -> 101.6 ms (the append is ~6 instructions per sample in a kernel
+    // that issues 190 per sample, plus a fill-count round trip per pass) and accumulate 1.5 -> 4.0 ms: off by default
+    int stage_dense = 0;
     int residency = 32;           // src/ form, pool scheduler: bounce-steps a pixel stays resident when a wave owns more pixels than it holds
     int sparse_lanes = 24;        // src/ form, pool scheduler: tracked-object march steps when at most this many lanes march (heavy waves: always)
     // src/ form, pool scheduler: cost-ordered ownership (rt_persistent.hpp, plan kernels in rt_kernels.hip)

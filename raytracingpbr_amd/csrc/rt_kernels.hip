@@ -70,6 +70,59 @@ __global__ void __launch_bounds__(256) accumulate_samples(const Params P) {
     *dst = acc;
 }
 
+// The same sum over the DENSE staging (rt_trace.hpp stage_sample): a block takes `acc_batch` consecutive items at a time (a multiple
+// of K and of the chunk: whole pixels, whole chunks), reads the chunks' records as they lie — in completion order, coalesced — and
+// drops each at its sample's place in LDS (the byte beside the record says which sample of the chunk it is); then one thread per
+// pixel adds the K records of its pixel in sample order, as above.  The pixel stride in LDS is odd (in words): the threads' reads
+// fall into different banks.
+__global__ void __launch_bounds__(256) accumulate_dense(const Params P) {
+    extern __shared__ float lds_rec[];
+    __shared__ uint32_t fill_s[128];
+    const uint32_t B = P.acc_batch, chunk = P.chunk, K = (uint32_t)P.K;
+    const uint32_t stride = 3u * K + ((3u * K) & 1u ? 0u : 1u);
+    const uint32_t n_batch = (P.total_items + B - 1u) / B;
+    const StageRec* stage = reinterpret_cast<const StageRec*>(P.stage);
+    uint32_t n_dep = 0;
+    for (uint32_t b = blockIdx.x; b < n_batch; b += gridDim.x) {
+        const uint32_t b0 = b * B;
+        const uint32_t nb = P.total_items - b0 < B ? P.total_items - b0 : B;
+        const uint32_t c0 = b0 / chunk, nc = (nb + chunk - 1u) / chunk;
+        if (threadIdx.x < nc) fill_s[threadIdx.x] = P.stage_fill[c0 + threadIdx.x];
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < nb; s += 256u) {
+            const uint32_t cl = chunk == 1u ? s : __umulhi(s, P.acc_magic_chunk);
+            const uint32_t sl = s - cl * chunk;
+            if (sl < fill_s[cl]) {
+                const StageRec r = stage[b0 + s];
+                const uint32_t i = cl * chunk + (uint32_t)P.stage_idx[b0 + s];     // the record's item, relative to the batch
+                const uint32_t pl = K == 1u ? i : __umulhi(i, P.acc_magic_k);     // its pixel ...
+                float* d = lds_rec + pl * stride + (i - pl * K) * 3u;              // ... and sample
+                d[0] = r.r, d[1] = r.g, d[2] = r.b;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_pix = nb / K, q0 = b0 / K;
+        for (uint32_t pl = threadIdx.x; pl < n_pix; pl += 256u) {
+            int x = 0, y = 0;
+            if (!pixel_of(P, q0 + pl, x, y)) continue;
+            float4* dst = P.image_buffer + ((size_t)x * P.cfg.height + y);
+            float4 acc = *dst;
+            const float* src = lds_rec + pl * stride;
+            for (uint32_t k = 0; k < K; k++) {
+                acc.x += src[3u * k];
+                acc.y += src[3u * k + 1u];
+                acc.z += src[3u * k + 2u];
+                acc.w += 1.0f;
+            }
+            *dst = acc;
+            n_dep += K;
+        }
+        __syncthreads();
+    }
+    n_dep = wave_sum(n_dep);
+    if ((threadIdx.x & 63) == 0 && n_dep) atomicAdd(&P.counters->shard[blockIdx.x & 63u][5], (unsigned long long)n_dep);
+}
+
 // -------------------------------------------------------------------------------------------
 // refresh() src/renderer.py:12-22
 __global__ void refresh_kernel(float4* image_buffer, rtpbr_ray* ray_buffer, float2* diff_buffer, float* diff_pixels,
@@ -409,7 +462,15 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler) {
     else RT_DISPATCH_KIND(trace_paths, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     return e == hipSuccess ? per_cu : 0;
 }
-void launch_accumulate(const Params& P, hipStream_t st) {
+void launch_accumulate(const Params& P, int n_cu, hipStream_t st) {
+    if (P.stage_dense) {
+        const uint32_t K = (uint32_t)P.K;
+        const size_t lds = (size_t)(P.acc_batch / K) * (3u * K + ((3u * K) & 1u ? 0u : 1u)) * sizeof(float);
+        const long long n_batch = ((long long)P.total_items + P.acc_batch - 1) / P.acc_batch;
+        const long long room = (long long)(n_cu > 0 ? n_cu : 256) * 8;
+        hipLaunchKernelGGL(accumulate_dense, dim3((unsigned)(n_batch < room ? n_batch : room)), dim3(256), lds, st, P);
+        return;
+    }
     int grid = (P.np + 255) / 256;
     hipLaunchKernelGGL(accumulate_samples, dim3(grid), dim3(256), 0, st, P);
 }

@@ -106,6 +106,37 @@ RT_D void shade_miss(const Params& P, PathRay& R, uint32_t& n_sky) {
 RT_D void write_sample(const Params& P, uint32_t item, vec3 col) {
     reinterpret_cast<StageRec*>(P.stage)[item] = StageRec{col.x, col.y, col.z};
 }
+// Dense staging (round 6; pool kernel, wave-uniform call).  The item-linear layout leaves the 6.4 GB of records of a headline
+// step as 11.1 GB of HBM writes: the records of one 128-byte line finish up to a path's lifetime apart and the line leaves
+// the L2 in between.  Here the lanes that finished in this pass append their records to the region of the chunk the item was claimed
+// with — a chunk belongs to ONE wave, so its fill count is that wave's to read-modify-write — in completion order, one contiguous
+// run per chunk and pass, and note which sample each is (one byte: chunk <= 256).  accumulate_dense undoes the permutation.
+RT_D void stage_sample(const Params& P, bool fin, uint32_t item, vec3 col, int lane) {
+    if (!P.stage_dense) {
+        if (fin) write_sample(P, item, col);
+        return;
+    }
+    unsigned long long m = __ballot(fin);
+    const uint32_t cid = item / P.chunk;
+    while (m) {
+        const int first = __ffsll((long long)m) - 1;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, first);
+        const bool mine = fin && cid == c;
+        const unsigned long long mm = __ballot(mine);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0));
+        uint32_t base = 0;
+        // (an atomic: the count lives in L2, whichever lane of the wave touched it last)
+        if (lane == first) base = atomicAdd(&P.stage_fill[c], (uint32_t)__popcll(mm));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+        if (mine) {
+            const uint32_t c0 = c * P.chunk;
+            const uint32_t slot = c0 + base + rank;
+            reinterpret_cast<StageRec*>(P.stage)[slot] = StageRec{col.x, col.y, col.z};
+            P.stage_idx[slot] = (uint8_t)(item - c0);
+        }
+        m &= ~mm;
+    }
+}
 
 RT_D void lds_wave_fence();
 // TOLERANCE FLAVOUR (RT_FAST_MATH): no staging.  The exact kernels stage one record per sample because image_buffer must be
@@ -743,7 +774,7 @@ RT_D void trace_paths_pool_impl(const Params& P) {
 #if RT_FAST_MATH
                 acc_add(P, A, (st == SL_HIT || st == SL_MISS) && !alive, R.item / (uint32_t)P.K, R.col, lane, n_dep);
 #else
-                if ((st == SL_HIT || st == SL_MISS) && !alive) write_sample(P, R.item, R.col);
+                stage_sample(P, (st == SL_HIT || st == SL_MISS) && !alive, R.item, R.col, lane);
 #endif
                 w_samples += (uint32_t)__popcll(__ballot((st == SL_HIT || st == SL_MISS) && !alive));
                 if (st == SL_HIT || st == SL_MISS) st = SL_EMPTY;
@@ -782,13 +813,12 @@ RT_D void trace_paths_pool_impl(const Params& P) {
                             alive = true;
                         }
                     }
-#if !RT_FAST_MATH
-                    else if (r == 0) write_sample(P, R.item, R.col);
-#endif
                     roulette0 = r == 0;
                 }
 #if RT_FAST_MATH
                 acc_add(P, A, roulette0, R.item / (uint32_t)P.K, R.col, lane, n_dep);
+#else
+                if (__any(roulette0)) stage_sample(P, roulette0, R.item, R.col, lane);
 #endif
                 w_samples += (uint32_t)__popcll(__ballot(roulette0));
                 if (resumed == ST_HIT || resumed == ST_MISS) {

@@ -187,6 +187,14 @@ struct Params {
     int32_t mlp_full;       // bunny: compute both 32-slot halves when at least this many wait, else the first 32
     // pointers
     float* stage;           // 3 floats per work item (StageRec)
+    // dense staging (round 6): a wave appends the records of a claimed chunk in COMPLETION order to the chunk's own region of `stage`
+    // (coalesced, no line stays partially written for a path's lifetime) with the sample's offset in the chunk beside it;
+    // accumulate_dense puts them back in sample order in LDS.  0 = item-linear records (stage[item])
+    int32_t stage_dense;
+    uint32_t acc_batch;     // accumulate_dense: items per block pass (a multiple of both K and chunk)
+    uint32_t acc_magic_k, acc_magic_chunk;   // floor(2^32 / d) + 1: __umulhi(i, magic) == i / d for i * d < 2^32
+    uint8_t* stage_idx;     // per record: item - first item of its chunk (chunk <= 256)
+    uint32_t* stage_fill;   // per chunk: records appended so far (zeroed before the launch)
     float* primary;         // per item: t_eval of the primary raycast, written by primary_rays, read by the pool kernel
     uint8_t* primary_code;  // per item: idx | state << 5 (32 objects, 5 states) — 5 bytes per item in all, not a float2 (round 6)
     int32_t primary_split;  // 1 = primary raycasts run in their own coherent lock-step kernel
