@@ -413,7 +413,7 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * configuration; for offline renders of a fixed scene),
  * "jit_waves" (waves per SIMD the run-time pool kernel is compiled for; 0 = as the ahead-of-time instances),
  * "chunk" (work items a wave claims per atomic, at most 8192; 0 = automatic: total / (waves x 64) clamped to [256, 1024]),
- * "stage_dense" (complete-path pool kernel; 1: a wave appends the finished samples of a claim to the claim's own
+ * "stage_dense" (complete-path pool kernel, run-time instances only — the code is compiled in on request; 1: a wave appends the finished samples of a claim to the claim's own
  * stretch of the staging in completion order, with one byte that says which sample each is, and the accumulate kernel puts them
  * back in sample order — the claim is then the largest size <= 256 that is a whole multiple or a whole fraction of the launch's
  * samples per pixel, and a launch that has none (or a "chunk" that is none) keeps the item-linear records; 0, the default:

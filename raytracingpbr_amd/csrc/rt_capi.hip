@@ -48,10 +48,12 @@ static int create_resources(rtpbr_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->objfull, sizeof(ObjFull) * MAX_OBJ));
-    HIP_TRY(hipMalloc(&c->work_counter, 64));
     HIP_TRY(hipMalloc(&c->team_counter, 1024 * 64));
-    HIP_TRY(hipMalloc(&c->counters, sizeof(Counters)));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    // the work counters of a launch and the claim counters of the complete-path kernels in one allocation: ONE fill per rtpbr_sample()
+    // (a fill is a dispatch of its own: ~15 us between two small launches)
+    HIP_TRY(hipMalloc(&c->counters, sizeof(Counters) + 64));
+    c->work_counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(c->counters) + sizeof(Counters));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters) + 64, c->stream));
     HIP_TRY(hipEventCreate(&c->ev_total0));
     HIP_TRY(hipEventCreate(&c->ev_total1));
     hipDeviceProp_t prop;
@@ -100,7 +102,6 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     rt_rccl_release(c);
     rt_jit_release(c->jit_mod);
     c->jit_mod = nullptr;
-    (void)hipFree(c->work_counter);
     (void)hipFree(c->team_counter);
     for (void* hb : c->host_blocks) (void)hipHostFree(hb);
     c->host_blocks.clear();
@@ -763,6 +764,7 @@ static void derive_launch(rtpbr_ctx* c, RtJitKey* key, bool* want, bool* strict_
         const bool aot_special = c->kind == KIND_BOXES && c->n_obj == 8 && P.box_sig != 0;
         if (c->jit >= 1 || !aot_special || c->precision) {
             *key = make_jit_key(c->kind, c->n_obj, c->objm, c->cfg, P, persistent, c->jit_bake, c->jit_waves, jit_bunny, c->precision);
+            key->dense = (c->stage_dense && !persistent && !c->precision) ? 1 : 0;
             *want = true;
         }
     } else if (c->jit == 2) {
@@ -839,7 +841,7 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
         P.sample_base = c->sample_base;
         NEXT_EVENT(c->ev, c->ev_used, a);
         NEXT_EVENT(c->ev, c->ev_used, b);
-        HIP_TRY(hipEventRecord(a, c->stream));
+        if (c->timed) HIP_TRY(hipEventRecord(a, c->stream));
         // pool scheduler unless asked otherwise: measured faster than one lane per pixel at every frame size from
         // 256x256 up (profiles/r03_src_*; round 2 switched at 2^20 pixels by a guess)
         const bool use_pool = c->scheduler != 0;
@@ -1001,7 +1003,7 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
             if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
         } else
             launch_persistent(P, c->kind, steps, c->stream);
-        HIP_TRY(hipEventRecord(b, c->stream));
+        if (c->timed) HIP_TRY(hipEventRecord(b, c->stream));
         c->sample_base += (uint32_t)steps;
         left -= steps;
     }
@@ -1067,6 +1069,7 @@ static int launch_split_steps(rtpbr_ctx* c, int steps) {
 static int sample_complete_path(rtpbr_ctx* c, int n) {
     Params& P = c->P;
     int left = n;
+    c->dense_launches = 0;
     while (left > 0) {
         const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
         // the tolerance flavour accumulates in LDS and adds to image_buffer directly: no staging, no accumulate kernel
@@ -1107,7 +1110,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
         // dense staging (rt_trace.hpp stage_sample, accumulate_dense): the claim must be whole pixels or a whole fraction of one, and
         // fit the record's one-byte offset; a launch that has no such claim size near the one wanted keeps the item-linear records
         P.stage_dense = 0;
-        if (c->stage_dense && !unstaged && P.scheduler == 1) {
+        if (c->stage_dense && c->jit_mod != nullptr && !unstaged && P.scheduler == 1) {      // (compiled into run-time instances only: RtJitKey::dense)
             long long lo = DENSE_CHUNK_MIN, hi = chunk < 64 ? 64 : chunk > (long long)DENSE_CHUNK_MAX ? (long long)DENSE_CHUNK_MAX : chunk, cc = 0;
             if (c->chunk > 0) lo = hi = c->chunk;       // a claim size that was asked for is kept as it is (or the records stay item-linear)
             if (lo >= (long long)DENSE_CHUNK_MIN && hi <= (long long)DENSE_CHUNK_MAX)
@@ -1117,6 +1120,7 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
             if (cc > 0 && unit <= (long long)DENSE_BATCH_MAX) {
                 P.chunk = (uint32_t)cc;
                 P.stage_dense = 1;
+                c->dense_launches++;
                 P.acc_batch = (uint32_t)(unit * ((long long)DENSE_BATCH_MAX / unit));
                 P.acc_magic_k = K > 1 ? (uint32_t)(0x100000000ULL / (unsigned long long)K) + 1u : 0u;
                 P.acc_magic_chunk = (uint32_t)(0x100000000ULL / (unsigned long long)cc) + 1u;
@@ -1126,26 +1130,27 @@ static int sample_complete_path(rtpbr_ctx* c, int n) {
                 HIP_TRY(hipMemsetAsync(P.stage_fill, 0, n_fill * sizeof(uint32_t), c->stream));
             }
         }
-        HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));   // [0] trace items, [1] primary groups
+        // [0] trace items, [1] primary groups: zeroed with the work counters by rtpbr_sample(); again before every further sub-launch
+        if (left != n) HIP_TRY(hipMemsetAsync(c->work_counter, 0, 2 * sizeof(unsigned int), c->stream));
         if (split) {
             NEXT_EVENT(c->evp, c->evp_used, pa);
             NEXT_EVENT(c->evp, c->evp_used, pb);
-            HIP_TRY(hipEventRecord(pa, c->stream));
+            if (c->timed) HIP_TRY(hipEventRecord(pa, c->stream));
             if (c->jit_mod) {
                 long long need = ((long long)P.total_items + 255) / 256, pg = (long long)c->n_cu * tune::PRIMARY_BLOCKS_PER_CU;
                 if (int r = rt_jit_launch(c->jit_mod->primary, P, (unsigned)(pg < need ? pg : need), c->stream)) return r;
             } else
                 launch_primary(P, c->kind, c->n_cu, c->stream);
-            HIP_TRY(hipEventRecord(pb, c->stream));
+            if (c->timed) HIP_TRY(hipEventRecord(pb, c->stream));
         }
         NEXT_EVENT(c->ev, c->ev_used, a);
         NEXT_EVENT(c->ev, c->ev_used, b);
-        HIP_TRY(hipEventRecord(a, c->stream));
+        if (c->timed) HIP_TRY(hipEventRecord(a, c->stream));
         if (c->jit_mod) {
             if (int r = rt_jit_launch(c->jit_mod->trace, P, (unsigned)grid, c->stream)) return r;
         } else
             launch_trace(P, c->kind, grid, c->stream);
-        HIP_TRY(hipEventRecord(b, c->stream));
+        if (c->timed) HIP_TRY(hipEventRecord(b, c->stream));
         if (!unstaged) launch_accumulate(P, c->n_cu, c->stream);
         c->sample_base += (uint32_t)K;
         left -= K;
@@ -1188,17 +1193,17 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters) + 64, c->stream));      // (+ the claim counters behind them)
     c->ev_used = 0;
     c->evp_used = 0;
-    c->timed = true;
-    HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
+    c->timed = c->timing != 0;
+    if (c->timed) HIP_TRY(hipEventRecord(c->ev_total0, c->stream));
     if (c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY) {
         if (int r = sample_persistent(c, n)) return r;
     } else {
         if (int r = sample_complete_path(c, n)) return r;
     }
-    HIP_TRY(hipEventRecord(c->ev_total1, c->stream));
+    if (c->timed) HIP_TRY(hipEventRecord(c->ev_total1, c->stream));
     HIP_TRY(hipGetLastError());
     return RTPBR_OK;
 }
@@ -1409,6 +1414,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
     else if (!strcmp(name, "mlp_lane_evals")) *out = h.mlp_lane_evals;
     else if (!strncmp(name, "dbg", 3) && name[3] >= '0' && name[3] <= '9' && !name[4]) *out = h.dbg[name[3] - '0'];
     else if (!strncmp(name, "dbg", 3) && name[3] >= 'a' && name[3] <= 'v' && !name[4]) *out = h.dbg[10 + name[3] - 'a'];
+    else if (!strcmp(name, "dense_launches")) *out = c->dense_launches;      // complete-path launches of the last rtpbr_sample() that staged densely (option stage_dense)
     else if (!strncmp(name, "plan_ge:", 8)) {
         // pixels whose recorded cost was at least <n> march steps when the current plan was made (whole buckets)
         *out = 0;
@@ -1439,7 +1445,7 @@ extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long l
 
 extern "C" int rtpbr_last_sample_ms(rtpbr_ctx* c, float* trace_ms, float* total_ms, int* launches) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
-    if (!c->timed) return fail(RTPBR_ESTATE, "no rtpbr_sample() call to time yet");
+    if (!c->timed) return fail(RTPBR_ESTATE, "no timed rtpbr_sample() call yet (option timing = 0 records no events)");
     if (int r = set_dev(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     float tr = 0.0f;
@@ -1458,7 +1464,7 @@ extern "C" int rtpbr_last_sample_ms(rtpbr_ctx* c, float* trace_ms, float* total_
 
 extern "C" int rtpbr_last_primary_ms(rtpbr_ctx* c, float* primary_ms, int* launches) {
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
-    if (!c->timed) return fail(RTPBR_ESTATE, "no rtpbr_sample() call to time yet");
+    if (!c->timed) return fail(RTPBR_ESTATE, "no timed rtpbr_sample() call yet (option timing = 0 records no events)");
     if (int r = set_dev(c)) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));
     float pr = 0.0f;
@@ -1588,6 +1594,11 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "refill_lanes")) {
         if (value < 1 || value > 64) return fail(RTPBR_EINVAL, "refill_lanes must be 1..64");
         c->refill_lanes = (int)value;
+    } else if (!strcmp(key, "timing")) {
+        // 1 (default): rtpbr_sample() brackets its kernels with events (rtpbr_last_sample_ms / rtpbr_last_primary_ms); 0: none — an event
+        // is a barrier packet with a completion signal, and four of them cost a launch of a few hundred microseconds a fifth of its time
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "timing must be 0 or 1");
+        c->timing = (int)value;
     } else if (!strcmp(key, "stage_dense")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "stage_dense must be 0 (item-linear staging) or 1 (records appended per claim in completion order)");
         c->stage_dense = (int)value;

@@ -42,6 +42,7 @@ struct RtJitKey {
     int form;                   // 0 = complete-path kernels, 1 = persistent-ray kernels (only those are compiled)
     int baked;                  // 1: the march table and the render configuration are baked into the code object
     int fast;                   // 1: the tolerance flavour (RT_FAST_MATH, rt_math.hpp): hardware sqrt / rcp / sin / exp, contraction
+    int dense;                  // 1: complete-path pool kernel compiled with the dense staging (RT_STAGE_DENSE, rt_trace.hpp stage_sample)
     const unsigned* table;      // n_obj x 16 words (ObjM blocks)
     unsigned cfg_words[sizeof(rtpbr_config) / 4];   // rtpbr_config with seed and frame zeroed
     unsigned extra[4];          // box_lazy, box_four_rho, box_rho2m, box_4rho2m (bit patterns)
@@ -115,7 +116,8 @@ struct rtpbr_ctx {
     int lazy_sqrt = 1;       // all-box scenes: nearest box on squared distances (nearest_boxes_lazy)
     uint32_t scene_sig = 0;
     ObjM objm[MAX_OBJ];      // march table in its general layout; P.objm is filled per launch (pack_objects)
-    unsigned int* work_counter = nullptr;
+    unsigned int* work_counter = nullptr;   // (behind `counters`, same allocation)
+    int timing = 1;               // option timing: events around the kernels of rtpbr_sample()
     Counters* counters = nullptr;
     // tiles
     int tile_w = 0, tile_h = 0, rank = 0, world = 1;
@@ -129,10 +131,12 @@ struct rtpbr_ctx {
     int ready_low = 4;
     int jit_waves = 0;            // waves per SIMD the run-time pool kernel is compiled for (0 = as the ahead-of-time instances)
     int chunk = 0;                // work items claimed per atomic by the pool kernels (0 = automatic)
-    // complete-path pool kernel: 1 = records appended per claim in completion order (rt_trace.hpp stage_sample).  Measured on the headline
-    // step (round 6): trace-kernel WRITE 11.06 -> 8.75 GB, but trace 96.3 -> 101.6 ms (the append is ~6 instructions per sample in a kernel
-    // that issues 190 per sample, plus a fill-count round trip per pass) and accumulate 1.5 -> 4.0 ms: off by default
+    // complete-path pool kernel: 1 = records appended per claim in completion order (rt_trace.hpp stage_sample; run-time instances only: the
+    // code is compiled in by -DRT_STAGE_DENSE=1).  Measured on the headline step (round 6): trace-kernel WRITE 11.06 -> 8.75 GB, but trace
+    // 96.3 -> 101.6 ms (the append is ~6 instructions per sample in a kernel that issues 190 per sample, plus a fill-count round trip per
+    // pass) and accumulate 1.5 -> 4.0 ms: off by default
     int stage_dense = 0;
+    unsigned long long dense_launches = 0;      // ... launches of the last rtpbr_sample() that did (counter "dense_launches")
     int residency = 32;           // src/ form, pool scheduler: bounce-steps a pixel stays resident when a wave owns more pixels than it holds
     int sparse_lanes = 24;        // src/ form, pool scheduler: tracked-object march steps when at most this many lanes march (heavy waves: always)
     // src/ form, pool scheduler: cost-ordered ownership (rt_persistent.hpp, plan kernels in rt_kernels.hip)

@@ -250,8 +250,8 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
             for (char ch : f) th = (th ^ (unsigned char)ch) * 1099511628211ull + 1;
     }
     char name[256];
-    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d%s_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, key.form, key.fast ? "_fast" : "", (unsigned long long)th, (unsigned long long)sh);
+    snprintf(name, sizeof name, "k%d_n%d_t%llx_s%x_c%d_w%d_f%d%s%s_b%016llx_%016llx", key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, key.fast ? "_fast" : "", key.dense ? "_dense" : "", (unsigned long long)th, (unsigned long long)sh);
     const std::string cdir = cache_dir();
     const std::string path = cdir + "/" + name + ".hsaco";
     if (!cdir.empty()) {
@@ -355,6 +355,7 @@ int rt_jit_build(const RtJitKey& key, std::string* out, bool* deterministic) {
         // Cornell headline 4974 -> 5366 Msamples/s, whole-frame L2 against the exact kernels 6.69e-4 -> 6.71e-4
         if (key.kind == 1) argv.insert(argv.begin() + 10, "-DRT_FAST_HW_SQRT=1");
     }
+    if (key.dense) argv.insert(argv.begin() + 10, "-DRT_STAGE_DENSE=1");
     if (key.baked) argv.insert(argv.begin() + 10, table_def);
     argv.insert(argv.begin() + 10, extra.begin(), extra.end());
     const int rc = run(argv, log);
@@ -416,8 +417,8 @@ static void evict_modules(std::vector<RtJitModule*>& victims) {
 // The instance of `key` on c's device, PINNED (rt_jit_release when the context stops using it).
 int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
     char id[224];
-    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_f%d_p%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
-             key.cull, key.waves, key.form, key.fast, (unsigned long long)baked_hash(key));
+    snprintf(id, sizeof id, "d%d_k%d_n%d_t%llx_s%x_c%d_w%d_f%d_p%d_e%d_b%llx", c->device, key.kind, key.n_obj, (unsigned long long)key.types, key.sig,
+             key.cull, key.waves, key.form, key.fast, key.dense, (unsigned long long)baked_hash(key));
     if (const char* e = getenv("RTPBR_JIT_EXTRA_FLAGS")) snprintf(id + strlen(id), sizeof id - strlen(id), "_x%zx", std::hash<std::string>()(e));
     {
         std::unique_lock<std::mutex> lock(g_mu);

@@ -111,7 +111,15 @@ RT_D void write_sample(const Params& P, uint32_t item, vec3 col) {
 // the L2 in between.  Here the lanes that finished in this pass append their records to the region of the chunk the item was claimed
 // with — a chunk belongs to ONE wave, so its fill count is that wave's to read-modify-write — in completion order, one contiguous
 // run per chunk and pass, and note which sample each is (one byte: chunk <= 256).  accumulate_dense undoes the permutation.
+// Compiled in by -DRT_STAGE_DENSE=1 (run-time instances, option stage_dense): merely present, the loop costs the ahead-of-time and the
+// unbaked instances 5 % (registers), so it is not.
+#ifndef RT_STAGE_DENSE
+#define RT_STAGE_DENSE 0
+#endif
 RT_D void stage_sample(const Params& P, bool fin, uint32_t item, vec3 col, int lane) {
+#if !RT_STAGE_DENSE
+    if (fin) write_sample(P, item, col);
+#else
     if (!P.stage_dense) {
         if (fin) write_sample(P, item, col);
         return;
@@ -136,6 +144,7 @@ RT_D void stage_sample(const Params& P, bool fin, uint32_t item, vec3 col, int l
         }
         m &= ~mm;
     }
+#endif
 }
 
 RT_D void lds_wave_fence();
@@ -818,7 +827,11 @@ RT_D void trace_paths_pool_impl(const Params& P) {
 #if RT_FAST_MATH
                 acc_add(P, A, roulette0, R.item / (uint32_t)P.K, R.col, lane, n_dep);
 #else
+#if RT_STAGE_DENSE
                 if (__any(roulette0)) stage_sample(P, roulette0, R.item, R.col, lane);
+#else
+                if (roulette0) write_sample(P, R.item, R.col);
+#endif
 #endif
                 w_samples += (uint32_t)__popcll(__ballot(roulette0));
                 if (resumed == ST_HIT || resumed == ST_MISS) {

@@ -18,7 +18,7 @@ for seed in range(lo, hi):
     o = run(OracleRenderer(sc, cfg), env, n, cfg.kernel_form == 1)
     co = o.counters()
     variants = [{}, {"primary_split": 2}]
-    if cfg.kernel_form == 0: variants.append({"stage_dense": 1, "primary_split": 2 * (seed % 2)})      # records appended per claim (round 6)
+    if cfg.kernel_form == 0: variants.append({"stage_dense": 1, "jit": 1, "primary_split": 2 * (seed % 2)})      # records appended per claim (round 6)
     if seed % 3 == 0: variants.append({"jit": 1, "jit_bake": seed % 2})      # run-time instance where the scene is eligible
     if cfg.kernel_form == 1:        # src/ form: the pool kernel's ownership / residency / culling choices, the lock-step kernel
         variants += [{"scheduler": 0}, {"grid_blocks": 1, "residency": 2}, {"grid_blocks": 3, "residency": 8, "sparse_lanes": 64, "jit": 1},

@@ -155,7 +155,7 @@ def test_schedule_independence():
                  {"lazy_sqrt": 0}, {"lazy_sqrt": 0, "specialize": 0, "scheduler": 0},
                  # the drain's culled wave march (round 5): never / for every wave once the work has run out; with and without its lean loop
                  {"drain_lanes": 0}, {"drain_lanes": 64}, {"drain_lanes": 64, "jit": 2, "chunk": 64}, {"drain_lanes": 3, "primary_lean": 0, "jit": 2, "jit_bake": 1},
-                 {"stage_dense": 1}, {"stage_dense": 1, "chunk": 48, "shade_lanes": 7, "jit": 2}):
+                 {"stage_dense": 1, "jit": 1}, {"stage_dense": 1, "chunk": 48, "shade_lanes": 7, "jit": 2}):
         r = Renderer(case.scene, case.cfg)
         for k, v in opts.items():
             r.set_option(k, v)
@@ -175,7 +175,7 @@ def test_schedule_independence():
 def test_dense_staging_equals_item_linear_records_and_the_oracle():
     """Round 6: the pool kernel appends a claim's records in COMPLETION order (rt_trace.hpp stage_sample) and
     accumulate_dense puts them back in sample order.  Samples per launch that are whole multiples / whole fractions of the claim
-    (and those that have no such claim size: 257, 5000 -> item-linear records), claims asked for, edge tiles with padding pixels,
+    (and those that have no such claim size: 257, 5000 -> item-linear records; counter "dense_launches" says which), claims asked for, edge tiles with padding pixels,
     the separate primary kernel, run-time instances and the staging split into several launches: the bits of option
     stage_dense = 0, and — at 12 spp — the oracle's."""
     case = case_by_name("cornell_v3_8b_wide")
@@ -183,13 +183,14 @@ def test_dense_staging_equals_item_linear_records_and_the_oracle():
     small = Config.cornell_v3(24, 16, 3, 8)
     small_sc = cornell_box("v3", aspect=24 / 16)
     o = OracleRenderer(sc, cfg); o.sample(12)
-    for opts in ({}, {"primary_split": 2}, {"jit": 2, "jit_bake": 1}, {"chunk": 96, "primary_split": 2}, {"chunk": 36}, {"chunk": 256, "jit": 2},
+    for opts in ({}, {"primary_split": 2}, {"jit": 2, "jit_bake": 1}, {"chunk": 96, "primary_split": 2}, {"chunk": 36}, {"chunk": 240},
                  {"staging_bytes": 1 << 20}, {"shade_lanes": 3, "swap_lanes": 2, "refill_lanes": 1}, {"drain_lanes": 64, "waves_per_cu": 1}):
         r = Renderer(sc, cfg)
-        r.set_option("stage_dense", 1)
+        r.set_option("stage_dense", 1); r.set_option("jit", 2)      # (compiled into run-time instances only)
         for k, v in opts.items():
             r.set_option(k, v)
         r.sample(12)
+        assert r.counter("dense_launches") >= 1, opts
         assert np.array_equal(bits(r.image_buffer), bits(o.image_buffer)), opts
         assert r.counters().deposits == o.counters().deposits, opts
         r.close()
@@ -197,10 +198,11 @@ def test_dense_staging_equals_item_linear_records_and_the_oracle():
         imgs = []
         for dense in (0, 1):
             r = Renderer(small_sc, small)
-            r.set_option("stage_dense", dense)
+            r.set_option("stage_dense", dense); r.set_option("jit", 2)
             if K % 2: r.set_option("primary_split", 2)
             r.set_tiles(16, 16, K % 2, 2)      # 24x16 in 16x16 tiles: the second column of tiles is half padding
             r.sample(K)
+            assert r.counter("dense_launches") == (1 if dense and K not in (257, 5000) else 0), (K, dense)
             r.sample(3)                        # a second launch on top (another claim size)
             imgs.append(bits(r.image_buffer).copy())
             dep = r.counters().deposits
