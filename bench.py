@@ -167,26 +167,37 @@ def measure(wl, r, steps, warmup, fence=None, gather=None, one_step_launches=Fal
             gather()
 
     fence = fence or r.sync
+    # Sub-millisecond launches (C1's steps, the one-step src/ launches) are timed WITHOUT the library's per-kernel events (option
+    # timing = 0: what a host that does not ask for kernel times sets; an event is ~4 us of idle queue between two small kernels);
+    # their kernel figures come from one further step with the events on, outside the timed region, scaled.
+    events_off = one_step_launches or not sync_every_step
+    if events_off:
+        r.set_option("timing", 0)
     for _ in range(warmup):
         step()
     fence()
     trace_ms = primary_ms = 0.0
     launches = primary_launches = 0
     t0 = time.perf_counter()
-    if not sync_every_step:
+    if events_off:
         for _ in range(steps):
             step()
+            if sync_every_step:
+                fence()
         fence()
         dt = time.perf_counter() - t0
+        r.set_option("timing", 1)
+        step()
         tr, _tot, n = r.last_sample_ms()
+        if one_step_launches:        # (the library keeps the events of the last rtpbr_sample() call only: scale the last launch)
+            tr, n = tr * wl.spp, n * wl.spp
         pr, pn = (0.0, 0) if form_src else r.last_primary_ms()
-        return {"dt": dt, "trace_ms": tr * steps, "launches": n * steps, "primary_ms": pr * steps, "primary_launches": pn * steps}
+        return {"dt": dt, "trace_ms": tr * steps, "launches": n * steps, "primary_ms": pr * steps, "primary_launches": pn * steps,
+                "events": "off in the timed region (option timing = 0); kernel figures from one further step, scaled"}
     for _ in range(steps):
         step()
         # HIP-event timing of the kernels; reading it waits for the step, which the timed region must wait for anyway
         tr, _tot, n = r.last_sample_ms()
-        if one_step_launches:        # (the library keeps the events of the last rtpbr_sample() call only: scale the last launch)
-            tr, n = tr * wl.spp, n * wl.spp
         trace_ms += tr
         launches += n
         if not form_src:
@@ -278,6 +289,8 @@ def side_config(name, a, device, rank0_of=1):
                                "note": "no staging in this flavour (LDS accumulators + f32 atomics); what remains is the primary records, 5 B per sample written and read"}
         except Exception:
             pass
+    if "events" in m:
+        out["events"] = m["events"]
     if name == "c3_valu":
         out["differs_from_c3_in"] = "mlp_mfma only (same pool kernel, same pass policy, same run-time instance)"
     r.close()
@@ -364,6 +377,7 @@ def frame_latency(a, device, W=768, H=432, frames=200):
     from raytracingpbr_amd import workloads
     wl = workloads.get("src", W, H, 1)
     r = make_renderer(wl, device, a, jit=not a.no_jit)
+    r.set_option("timing", 0)                 # a viewer does not ask for kernel times: no events between the kernels (they are on for sample_kernels_ms below)
     for _ in range(96):                       # the cost plan (64 steps on record) and the run-time instance exist before the timed frames
         r.render()
     from raytracingpbr_amd.renderer import BUF_IMAGE_PIXELS
@@ -403,6 +417,7 @@ def frame_latency(a, device, W=768, H=432, frames=200):
     dt_dev = time.perf_counter() - t0
     # device time of the sample kernels (gen + march + shade of one bounce-step), HIP events, mean over 64 frames (a single launch
     # varies by +-10 %: the launch is as long as its slowest wave)
+    r.set_option("timing", 1)
     tr = 0.0
     for _ in range(64):
         r.render()
@@ -417,6 +432,7 @@ def frame_latency(a, device, W=768, H=432, frames=200):
             "ms_per_frame_pipelined": round(dt_pipe / frames * 1e3, 4), "frames_per_s_pipelined": round(frames / dt_pipe, 1),
             "pipelined": "rtpbr_read_buffer_async into two page-locked buffers: frame k's copy overlaps frame k+1's sample kernels, every frame is delivered to the host (one frame later); "
                          "a consumer on the GPU takes rtpbr_buffer_device_ptr and pays device_ms_per_frame",
+            "events": "option timing = 0 in the frame loops (no HIP events between the kernels), 1 for sample_kernels_ms",
             "host_buffer": "ms_per_frame reads image_pixels into one page-locked host buffer (rtpbr_host_alloc) every frame; ms_per_frame_fresh_host_array allocates a numpy array per frame (round 4's figure)",
             "device_ms_per_frame": round(dt_dev / frames * 1e3, 4), "sample_kernels_ms": round(tr, 4),
             "readback_bytes_per_frame": int(np.asarray(px).nbytes), "run_time_kernels": split,

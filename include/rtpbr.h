@@ -348,7 +348,9 @@ int rtpbr_get_counters(rtpbr_ctx* ctx, rtpbr_counters* out);         /* blocking
  * were needed for; their ratio / 32 is the slot utilisation of the MLP.  EINVAL for an unknown name. */
 int rtpbr_get_counter(rtpbr_ctx* ctx, const char* name, unsigned long long* out);
 /* Device time (HIP events on the context's stream) of the trace kernel launches and of
- * all kernels of the last rtpbr_sample() call, in milliseconds (blocking). */
+ * all kernels of the last rtpbr_sample() call, in milliseconds (blocking).  Option "timing" = 0 records no events
+ * (every event is a few microseconds of idle queue between two small kernels: 8 us of a 160 us one-step launch) —
+ * these two calls then return RTPBR_ESTATE. */
 int rtpbr_last_sample_ms(rtpbr_ctx* ctx, float* trace_ms, float* total_ms, int* launches);
 /* Device time of the primary_rays launches of the last rtpbr_sample() call (0 launches when
  * the primary raycasts ran inside the trace kernel: option "primary_split" 0, neural SDF). */
@@ -413,6 +415,8 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * configuration; for offline renders of a fixed scene),
  * "jit_waves" (waves per SIMD the run-time pool kernel is compiled for; 0 = as the ahead-of-time instances),
  * "chunk" (work items a wave claims per atomic, at most 8192; 0 = automatic: total / (waves x 64) clamped to [256, 1024]),
+ * "timing" (1, the default: rtpbr_sample() brackets its kernels with HIP events for rtpbr_last_sample_ms /
+ * rtpbr_last_primary_ms; 0: none),
  * "stage_dense" (complete-path pool kernel, run-time instances only — the code is compiled in on request; 1: a wave appends the finished samples of a claim to the claim's own
  * stretch of the staging in completion order, with one byte that says which sample each is, and the accumulate kernel puts them
  * back in sample order — the claim is then the largest size <= 256 that is a whole multiple or a whole fraction of the launch's

@@ -13,6 +13,7 @@
 namespace rt {
 void launch_trace(const Params& P, int kind, int grid, hipStream_t st);
 void launch_accumulate(const Params& P, int n_cu, hipStream_t st);
+void launch_zero(void* p, size_t bytes, hipStream_t st);      // a small fill as a kernel of our own (bytes % 16 == 0)
 void launch_persistent(const Params& P, int kind, int steps, hipStream_t st);
 void launch_persistent_pool(const Params& P, int kind, int steps, int grid, hipStream_t st);
 int persistent_pool_blocks_per_cu(int kind);
@@ -118,6 +119,7 @@ struct rtpbr_ctx {
     ObjM objm[MAX_OBJ];      // march table in its general layout; P.objm is filled per launch (pack_objects)
     unsigned int* work_counter = nullptr;   // (behind `counters`, same allocation)
     int timing = 1;               // option timing: events around the kernels of rtpbr_sample()
+    bool total1_recorded = false; // the last rtpbr_sample() recorded ev_total1 (work followed its last timed kernel)
     Counters* counters = nullptr;
     // tiles
     int tile_w = 0, tile_h = 0, rank = 0, world = 1;
@@ -194,7 +196,7 @@ struct rtpbr_ctx {
     int ev_used = 0;
     std::vector<hipEvent_t> evp;   // pairs around the primary_rays launches
     int evp_used = 0;
-    hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr;
+    hipEvent_t ev_total1 = nullptr;      // end of the last rtpbr_sample() where work follows its last timed kernel (its start = its first event)
     bool timed = false;
     int n_cu = 256;
     // run-time compiled instance of the current scene (rt_jit.hip): -1 = when no ahead-of-time specialisation serves

@@ -462,6 +462,15 @@ int trace_blocks_per_cu(int kind, int n_obj, uint32_t box_sig, int scheduler) {
     else RT_DISPATCH_KIND(trace_paths, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0));
     return e == hipSuccess ? per_cu : 0;
 }
+// Small fills as a kernel of our own: a hipMemsetAsync of a few KB is a blit dispatch with ~10 us of idle queue on either side
+// (rocprofv3 kernel trace of the one-step src/ launches: shade -> 11 us -> fill 3.7 us -> 10.5 us -> gen, while gen -> march -> shade
+// follow each other without a gap): 25 us of a 160 us launch.
+__global__ void __launch_bounds__(256) zero_words_kernel(uint4* p, int n16) {
+    for (int i = threadIdx.x; i < n16; i += 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+void launch_zero(void* p, size_t bytes, hipStream_t st) {      // bytes: a multiple of 16, p 16-byte aligned
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<uint4*>(p), (int)(bytes / 16));
+}
 void launch_accumulate(const Params& P, int n_cu, hipStream_t st) {
     if (P.stage_dense) {
         const uint32_t K = (uint32_t)P.K;

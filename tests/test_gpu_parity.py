@@ -211,6 +211,28 @@ def test_dense_staging_equals_item_linear_records_and_the_oracle():
         assert np.array_equal(imgs[0], imgs[1]), K
 
 
+def test_timing_option_only_removes_the_events():
+    """Option timing = 0: rtpbr_sample() records no HIP events (bench.py times its small launches that way) — same bits in both
+    kernel forms, rtpbr_last_sample_ms / rtpbr_last_primary_ms answer ESTATE until a timed call has run, and a timed call reports
+    a total that covers its kernels."""
+    for name, n in (("cornell_v3_8b_wide", 5), ("src_persistent", 3)):
+        case = case_by_name(name)
+        a = Renderer(case.scene, case.cfg); case.run(a)
+        b = Renderer(case.scene, case.cfg); b.set_option("timing", 0); case.run(b)
+        assert np.array_equal(bits(a.image_buffer), bits(b.image_buffer)), name
+        assert a.counters().samples == b.counters().samples
+        with pytest.raises(RtpbrError):
+            b.last_sample_ms()
+        with pytest.raises(RtpbrError):
+            b.last_primary_ms()
+        b.set_option("timing", 1); b.sample(n)
+        tr, tot, launches = b.last_sample_ms()
+        assert launches >= 1 and 0.0 < tr <= tot * 1.001, (name, tr, tot)
+        tr, tot, launches = a.last_sample_ms()
+        assert launches >= 1 and 0.0 < tr <= tot * 1.001, (name, tr, tot)
+        a.close(); b.close()
+
+
 def r_pixels(cfg, rank):
     """pixels of a 24x16 frame owned by `rank` of 2 with 16x16 tiles dealt round-robin (tile 0: 16x16, tile 1: 8x16)"""
     return 16 * 16 if rank == 0 else (cfg.width - 16) * 16
