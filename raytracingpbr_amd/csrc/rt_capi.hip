@@ -51,9 +51,13 @@ static int create_resources(rtpbr_ctx* c) {
     HIP_TRY(hipMalloc(&c->team_counter, 1024 * 64));
     // the work counters of a launch and the claim counters of the complete-path kernels in one allocation: ONE fill per rtpbr_sample()
     // (a fill is a dispatch of its own: ~15 us between two small launches)
-    HIP_TRY(hipMalloc(&c->counters, sizeof(Counters) + 64));
+    constexpr size_t counters_bytes = (sizeof(Counters) + 64 + 255) / 256 * 256;
+    HIP_TRY(hipMalloc(&c->counters_buf[0], 2 * counters_bytes));
+    c->counters_buf[1] = reinterpret_cast<Counters*>(reinterpret_cast<char*>(c->counters_buf[0]) + counters_bytes);
+    HIP_TRY(hipMemsetAsync(c->counters_buf[0], 0, 2 * counters_bytes, c->stream));
+    c->counters_clean[0] = c->counters_clean[1] = true;
+    c->counters = c->counters_buf[0];
     c->work_counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(c->counters) + sizeof(Counters));
-    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters) + 64, c->stream));
     // timing events carry no data to the host (a read-back synchronises the stream itself): without the system-scope fence an event
     // costs the queue less (rocprofv3: ~10 us of idle queue per default event between two small kernels)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_total1, hipEventDisableSystemFence));
@@ -107,7 +111,7 @@ extern "C" int rtpbr_destroy(rtpbr_ctx* c) {
     for (void* hb : c->host_blocks) (void)hipHostFree(hb);
     c->host_blocks.clear();
     c->host_sizes.clear();
-    (void)hipFree(c->counters);
+    (void)hipFree(c->counters_buf[0]);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evp) (void)hipEventDestroy(e);
     if (c->ev_total1) (void)hipEventDestroy(c->ev_total1);
@@ -1193,8 +1197,19 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     for (int i = 0; i < c->n_obj; i++)
         if (c->obj[i].type == RTPBR_SHAPE_BUNNY && !c->bunny) return fail(RTPBR_ESTATE, "bunny shape needs rtpbr_set_shape_data first");
     if (c->cfg.sky_kind == RTPBR_SKY_ENVMAP && !c->env) return fail(RTPBR_ESTATE, "sky_kind ENVMAP needs rtpbr_set_env first");
-    static_assert((sizeof(Counters) + 64) % 16 == 0, "launch_zero fills 16-byte words");
-    launch_zero(c->counters, sizeof(Counters) + 64, c->stream);      // (+ the claim counters behind them)
+    static_assert((sizeof(Counters) + 64) % 16 == 0, "zero_next_counters / launch_zero fill 16-byte words");
+    // This call's work counters (+ the claim counters behind them): the buffer whose turn it is, zeroed by the previous call's kernels
+    // (or here, if that call launched none); this call's kernels zero the other one.
+    const int turn = c->counters_turn;
+    c->counters = c->counters_buf[turn];
+    c->work_counter = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(c->counters) + sizeof(Counters));
+    if (!c->counters_clean[turn]) launch_zero(c->counters, sizeof(Counters) + 64, c->stream);
+    P.counters = c->counters;
+    P.work_counter = c->work_counter;
+    P.counters_next = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY ? c->counters_buf[turn ^ 1] : nullptr;
+    c->counters_clean[turn] = false;
+    c->counters_clean[turn ^ 1] = false;
+    c->counters_turn = turn ^ 1;
     c->ev_used = 0;
     c->evp_used = 0;
     c->timed = c->timing != 0;
@@ -1211,6 +1226,8 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
         c->total1_recorded = true;
     }
     HIP_TRY(hipGetLastError());
+    // (the first kernel of every src/ path zeroed the other buffer: persistent pool / persistent steps / src_gen)
+    c->counters_clean[c->counters_turn] = n > 0 && c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY;
     return RTPBR_OK;
 }
 

@@ -120,7 +120,10 @@ struct rtpbr_ctx {
     unsigned int* work_counter = nullptr;   // (behind `counters`, same allocation)
     int timing = 1;               // option timing: events around the kernels of rtpbr_sample()
     bool total1_recorded = false; // the last rtpbr_sample() recorded ev_total1 (work followed its last timed kernel)
-    Counters* counters = nullptr;
+    Counters* counters = nullptr;        // the buffer of the LAST rtpbr_sample() call (what rtpbr_get_counters reads): counters_buf[0] or [1]
+    Counters* counters_buf[2] = {nullptr, nullptr};   // taken in turn; a call's kernels zero the other one for the next call (zero_next_counters)
+    bool counters_clean[2] = {false, false};
+    int counters_turn = 0;
     // tiles
     int tile_w = 0, tile_h = 0, rank = 0, world = 1;
     // progress

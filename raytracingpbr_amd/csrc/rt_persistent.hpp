@@ -13,6 +13,7 @@ namespace rt {
 template <int KIND, int NOBJ = 0, uint32_t SIG = 0>
 RT_D void persistent_steps_impl(const Params& P, int steps) {
     __shared__ ObjFull lds_obj[MAX_OBJ];
+    zero_next_counters(P);
     stage_objects(P, lds_obj);
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     int px = 0, py = 0;
@@ -759,6 +760,7 @@ RT_D void persistent_pool_impl(const Params& P, int steps) {
 #if RT_POOL_OP
     __shared__ float4 xch_all[4][8];
 #endif
+    zero_next_counters(P);
     stage_objects(P, lds_obj);
 
     const unsigned long long t_wave0 = __builtin_readcyclecounter();

@@ -26,6 +26,7 @@ RT_D uint32_t mw_pack(uint32_t state, int idx, uint32_t cnt) { return state | ((
 
 template <int KIND>
 RT_D void src_gen_impl(const Params& P) {
+    zero_next_counters(P);
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     int px = 0, py = 0;
     bool valid = q < (uint32_t)P.np && pixel_of(P, q, px, py);

@@ -42,6 +42,14 @@ RT_D void flush_counters(const Params& P, uint32_t steps, uint32_t raycasts, uin
 }
 
 // Stage the per-lane-indexed object table (T4: transform + material) in LDS.
+// (the src/ kernels only — persistent pool, persistent steps, src_gen: their launches are the 0.2 ms ones; in the complete-path pool kernel
+// the extra pointer cost the ahead-of-time instances 2 % — 3 505 -> 3 430 Msamples/s — for 4.5 us per launch: those calls fill with launch_zero)
+RT_D void zero_next_counters(const Params& P) {
+    if (P.counters_next != nullptr && blockIdx.x == 0) {
+        uint4* p = reinterpret_cast<uint4*>(P.counters_next);
+        for (int i = threadIdx.x; i < (int)((sizeof(Counters) + 64) / 16); i += 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
 RT_D void stage_objects(const Params& P, ObjFull* lds_obj) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(P.objfull);
     uint32_t* dst = reinterpret_cast<uint32_t*>(lds_obj);

@@ -223,6 +223,9 @@ struct Params {
     const float* bunny;     // 625 weights
     unsigned int* work_counter;
     Counters* counters;
+    // the work counters (and the claim counters behind them) of the NEXT rtpbr_sample() call, zeroed by the first block of this call's
+    // kernels (zero_next_counters): two buffers taken in turn — a fill of its own between two small launches is 4.5 us of 160
+    Counters* counters_next;
     // src/ pool kernel, cost-ordered ownership (rt_plan.hpp): march steps per local pixel since the last plan (accumulated at
     // write-back), the local pixels ordered by that cost (heaviest first; nullptr = no plan yet: identity), and the plan
     uint32_t* cost_buffer;
