@@ -23,6 +23,15 @@ out = {"workload": f"Cornell Box v3 {W}x{H}, {SPP} spp, {B} bounces, seed 0", "i
        "hip_seconds": round(tg, 3), "oracle_seconds": round(to, 1), "oracle_threads": usable_cores(),
        "mean_radiance": [float(x) for x in (a[..., :3] / a[..., 3:4]).mean(axis=(0, 1))],
        "options": json.loads(os.environ.get("OPTS", "{}")), "run_time_instance_active": bool(g.counter("jit_active"))}
+# further option sets (OPTS2='[{...}, {...}]'): each rendered by the HIP path again and compared with the first render bit for bit
+for extra in json.loads(os.environ.get("OPTS2", "[]")):
+    g2 = Renderer(sc, cfg)
+    for k, v in extra.items(): g2.set_option(k, v)
+    g2.refresh(); g2.sample(SPP); g2.sync()
+    out.setdefault("further_option_sets", []).append({"options": extra, "image_buffer_bit_identical_to_first": bool(np.array_equal(
+        np.ascontiguousarray(g2.image_buffer).view(np.uint32), np.ascontiguousarray(a).view(np.uint32))), "counters_identical": ctr(g2.counters()) == ctr(cg),
+        "dense_launches": int(g2.counter("dense_launches"))})
+    g2.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fullsize_parity.json"), "w"), indent=1)
 print(json.dumps(out))
