@@ -383,6 +383,11 @@ int rtpbr_get_stream(rtpbr_ctx* ctx, void** stream);
  * "split_head" (split march kernel: the
  * cost-ordered list's heavy head interleaved over the groups, one entry per group, instead of filling the first groups: -1 = for
  * frames of at most 600 000 pixels (default), 0 never, 1 always),
+ * "src_lazy" (one-step launches of the persistent-ray form, i.e. the wavefront split; 1, default: a launch leaves its shading to the
+ * next launch's gen pass — one pass over ray_buffer instead of two, one kernel less per launch — and every call that could see the
+ * difference launches it first: readers and writers of ray_buffer (rtpbr_buffer_device_ptr of ray_buffer ends the lazy mode for the
+ * context), rtpbr_get_counter(s), every setter, rtpbr_refresh, a launch of another kind; rtpbr_post_process and reads of the image
+ * buffers do not need it.  0: every launch shades.  Same bits either way),
  * "env_packed" (1, default: an environment uploaded as 8-bit texels is read as RGBA8 texels + the 256-entry table of
  * (c / 255 * exposure)^gamma — the same floats, a quarter of the bytes, same speed; 0 = float4 texels),
  * "src_track" (same kernel: 1 = tracked-object march steps — a lane that knows a lower bound of every object but the

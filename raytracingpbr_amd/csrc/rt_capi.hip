@@ -40,6 +40,22 @@ static int set_dev(rtpbr_ctx* c) {
     return RTPBR_OK;
 }
 
+// The lazy shading of the split's one-step launches (rt_ctx.hpp src_lazy): launch what the last such launch left for the next one's gen
+// pass.  Called by everything that could tell the difference.
+static int flush_shade(rtpbr_ctx* c) {
+    if (!c->shade_pending) return RTPBR_OK;
+    c->shade_pending = false;
+    if (int r = set_dev(c)) return r;
+    rtpbr_ctx::Params& P = c->P;
+    const uint32_t keep = P.sample_base;
+    P.sample_base = c->shade_pending_base;
+    int rc = RTPBR_OK;
+    if (c->jit_mod) rc = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)(((long long)P.np + 255) / 256), c->stream);
+    else launch_src_shade(P, c->kind, c->stream);
+    P.sample_base = keep;
+    return rc;
+}
+
 extern "C" const char* rtpbr_last_error(void) { return g_err; }
 extern "C" const char* rtpbr_backend(void) { return "hip-gfx950"; }
 
@@ -177,6 +193,7 @@ extern "C" int rtpbr_set_config(rtpbr_ctx* c, const rtpbr_config* cfg) {
     if (cfg->max_raymarch <= 0 || cfg->max_raytrace <= 0) return fail(RTPBR_EINVAL, "max_raymarch/max_raytrace must be > 0");
     if (int r = check_local_pixels(cfg->width, cfg->height, c->tile_w, c->tile_h, c->world)) return r;
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     bool realloc_buf = (!c->have_cfg || c->cfg.width != cfg->width || c->cfg.height != cfg->height) && !c->headless;
     c->cfg = *cfg;
     c->P.cfg = *cfg;
@@ -301,6 +318,7 @@ extern "C" int rtpbr_set_scene(rtpbr_ctx* c, const rtpbr_object* objs, int n, in
     for (int i = 0; i < n; i++)   // validate before touching the context
         if (objs[i].type < RTPBR_SHAPE_NONE || objs[i].type > RTPBR_SHAPE_BUNNY) return fail(RTPBR_EINVAL, "unknown shape type");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     ObjFull full[MAX_OBJ];
     memset(full, 0, sizeof full);
     bool all_box = true, all_bunny = true, any_bunny = false;
@@ -507,6 +525,7 @@ extern "C" int rtpbr_get_scene(rtpbr_ctx* c, rtpbr_object* objs, int n) {
 // thin-lens frame, src/camera.py:11-31 (same operation order as the oracle's camera_frame)
 extern "C" int rtpbr_set_camera(rtpbr_ctx* c, const rtpbr_camera* cam) {
     if (!c || !cam) return fail(RTPBR_EINVAL, "null argument");
+    if (int r = flush_shade(c)) return r;
     c->cam = *cam;
     vec3 lf = mk(cam->lookfrom[0], cam->lookfrom[1], cam->lookfrom[2]);
     vec3 la = mk(cam->lookat[0], cam->lookat[1], cam->lookat[2]);
@@ -539,6 +558,7 @@ extern "C" int rtpbr_set_env(rtpbr_ctx* c, const void* texels, int w, int h, int
     if (w <= 0 || h <= 0) return fail(RTPBR_EINVAL, "bad env size");
     if (fmt != RTPBR_ENV_RGB8 && fmt != RTPBR_ENV_RGB32F) return fail(RTPBR_EINVAL, "bad env format");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     size_t n = (size_t)w * h;
     std::vector<float4> host(n);
     if (fmt == RTPBR_ENV_RGB8) {
@@ -581,6 +601,7 @@ extern "C" int rtpbr_set_shape_data(rtpbr_ctx* c, int shape, const float* data, 
     if (!c || !data) return fail(RTPBR_EINVAL, "null argument");
     if (shape != RTPBR_SHAPE_BUNNY || n != 625) return fail(RTPBR_EINVAL, "only the bunny MLP (625 weights) takes shape data");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     // device layout: the hidden layers' matrices in chain order (rt_device.hpp): [k][i][m][j] <- caller's [k][m][i][j]
     float dev[625];
     memcpy(dev, data, sizeof dev);
@@ -600,6 +621,7 @@ extern "C" int rtpbr_set_tiles(rtpbr_ctx* c, int tw, int th, int rank, int world
     if (!c) return fail(RTPBR_EINVAL, "null ctx");
     if (world < 1 || rank < 0 || rank >= world) return fail(RTPBR_EINVAL, "bad rank/world");
     if (world > 1 && (tw <= 0 || th <= 0)) return fail(RTPBR_EINVAL, "tile size must be > 0 when world > 1");
+    if (int r = flush_shade(c)) return r;
     c->tile_w = tw;
     c->tile_h = th;
     c->rank = rank;
@@ -635,6 +657,7 @@ enum : unsigned { W_IMAGE_BUFFER = 1u << RTPBR_BUF_IMAGE_BUFFER, W_IMAGE_PIXELS 
 extern "C" int rtpbr_refresh(rtpbr_ctx* c) {
     if (!c || !c->have_cfg) return fail(RTPBR_ESTATE, "set_config first");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER | W_DIFF_PIXELS)) return r;
     size_t n = (size_t)c->cfg.width * c->cfg.height;
     launch_refresh(c->image_buffer, c->ray_buffer, c->diff_buffer, c->diff_pixels, c->cfg.adaptive_sampling, n, c->stream);
@@ -965,6 +988,7 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
             if (c->src_split > 0 && steps <= c->src_split) {
                 if (int r = launch_split_steps(c, steps)) return r;
             } else {
+                if (int r = flush_shade(c)) return r;
                 // A chain-bound launch hands the head of the cost-ordered list to the chain kernel (rt_chain.hpp), which runs
                 // BESIDE the pool kernel on a second stream: forked after the plan, joined before anything else touches the
                 // buffers.  Its grid covers the largest chain set a plan can make; waves without an entry leave at once.
@@ -1005,8 +1029,10 @@ static int sample_persistent(rtpbr_ctx* c, int n) {
             }
         } else if (c->jit_mod) {
             if (int r = rt_jit_launch_steps(c->jit_mod->persistent_steps, P, steps, (unsigned)((P.np + 255) / 256), c->stream)) return r;
-        } else
+        } else {
+            if (int r = flush_shade(c)) return r;
             launch_persistent(P, c->kind, steps, c->stream);
+        }
         if (c->timed) HIP_TRY(hipEventRecord(b, c->stream));
         c->sample_base += (uint32_t)steps;
         left -= steps;
@@ -1052,16 +1078,30 @@ static int launch_split_steps(rtpbr_ctx* c, int steps) {
     P.n_teams = (int)(mgrid < c->n_cu ? mgrid : c->n_cu);
     if (P.n_teams > tune::MARCH_MAX_TEAMS) P.n_teams = tune::MARCH_MAX_TEAMS;
     int rc = RTPBR_OK;
+    // lazy shading: a step's shading rides with the next step's gen pass (src_shade_gen) — flush_shade() launches it when something
+    // else wants to see ray_buffer or the counters first
+    const bool lazy = c->src_lazy != 0 && !c->ray_ptr_out;
     for (int i = 0; i < steps && rc == RTPBR_OK; i++) {
         P.sample_base = c->sample_base + (uint32_t)i;
+        const bool shade_first = c->shade_pending, count = c->shade_pending_same_call;
+        if (shade_first) {
+            P.shade_base = c->shade_pending_base;
+            c->shade_pending = false;
+        }
         if (c->jit_mod) {
-            rc = rt_jit_launch(c->jit_mod->src_gen, P, (unsigned)need, c->stream);
+            rc = rt_jit_launch(!shade_first ? c->jit_mod->src_gen : count ? c->jit_mod->src_shade_gen_count : c->jit_mod->src_shade_gen, P, (unsigned)need, c->stream);
             if (rc == RTPBR_OK) rc = rt_jit_launch(c->jit_mod->src_march, P, (unsigned)mgrid, c->stream);
-            if (rc == RTPBR_OK) rc = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)need, c->stream);
+            if (rc == RTPBR_OK && !lazy) rc = rt_jit_launch(c->jit_mod->src_shade, P, (unsigned)need, c->stream);
         } else {
-            launch_src_gen(P, c->kind, c->stream);
+            if (shade_first) launch_src_shade_gen(P, c->kind, count, c->stream);
+            else launch_src_gen(P, c->kind, c->stream);
             launch_src_march(P, c->kind, (int)mgrid, c->stream);
-            launch_src_shade(P, c->kind, c->stream);
+            if (!lazy) launch_src_shade(P, c->kind, c->stream);
+        }
+        if (lazy && rc == RTPBR_OK) {
+            c->shade_pending = true;
+            c->shade_pending_base = P.sample_base;
+            c->shade_pending_same_call = true;
         }
     }
     P.sparse_lanes = sparse_saved;
@@ -1073,6 +1113,7 @@ static int launch_split_steps(rtpbr_ctx* c, int steps) {
 static int sample_complete_path(rtpbr_ctx* c, int n) {
     Params& P = c->P;
     int left = n;
+    if (int r = flush_shade(c)) return r;
     c->dense_launches = 0;
     while (left > 0) {
         const bool split_ok = c->primary_split && P.scheduler == 1 && c->kind != KIND_BUNNY && c->kind != KIND_MIXED;
@@ -1169,6 +1210,16 @@ extern "C" int rtpbr_sample(rtpbr_ctx* c, int n) {
     if (int r = set_dev(c)) return r;
     // (diff_buffer: instrumented builds write their per-wave records over it)
     if (int r = rt_order_after_reads(c, W_IMAGE_BUFFER | W_RAY_BUFFER | W_DIFF_BUFFER)) return r;
+    // A shading the previous call left pending (lazy shading of one-step launches) rides along only if this call is again a launch of the
+    // wavefront split; otherwise it is launched now, while the previous call's work counters are still the current ones
+    {
+        const long long steps = (long long)n * c->cfg.steps_per_launch;
+        const bool split_again = c->cfg.kernel_form == RTPBR_FORM_PERSISTENT_RAY && c->scheduler != 0 && c->src_split > 0 && steps >= 1 &&
+                                 steps <= c->src_split && c->src_lazy != 0 && !c->ray_ptr_out;
+        if (!split_again)
+            if (int r = flush_shade(c)) return r;
+        c->shade_pending_same_call = false;
+    }
     Params& P = c->P;
     RtJitKey key{};
     bool want_jit = false, strict_error = false;
@@ -1273,6 +1324,8 @@ extern "C" int rtpbr_read_buffer(rtpbr_ctx* c, int which, void* dst, size_t nbyt
     if (int r = buf_ptr(c, which, &p, &n)) return r;
     if (!dst || nbytes != n) return fail(RTPBR_EINVAL, "destination size does not match the buffer");
     if (int r = set_dev(c)) return r;
+    if (which == RTPBR_BUF_RAY_BUFFER)
+        if (int r = flush_shade(c)) return r;
     HIP_TRY(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RTPBR_OK;
@@ -1284,6 +1337,10 @@ extern "C" int rtpbr_buffer_device_ptr(rtpbr_ctx* c, int which, void** device_pt
     size_t n;
     if (int r = buf_ptr(c, which, &p, &n)) return r;
     if (!device_ptr) return fail(RTPBR_EINVAL, "rtpbr_buffer_device_ptr: result pointer is required");
+    if (which == RTPBR_BUF_RAY_BUFFER) {      // its holder reads ray_buffer unannounced: shade now, and with every launch from here on
+        if (int r = flush_shade(c)) return r;
+        c->ray_ptr_out = true;
+    }
     *device_ptr = p;
     if (nbytes) *nbytes = n;
     return RTPBR_OK;
@@ -1293,6 +1350,8 @@ extern "C" int rtpbr_read_buffer_async(rtpbr_ctx* c, int which, void* dst, size_
     void* p;
     size_t n;
     if (int r = buf_ptr(c, which, &p, &n)) return r;
+    if (which == RTPBR_BUF_RAY_BUFFER)
+        if (int r = flush_shade(c)) return r;
     if (!dst || !ticket || nbytes != n) return fail(RTPBR_EINVAL, "rtpbr_read_buffer_async: destination, ticket and the buffer's exact size are required");
     bool pinned = false;
     for (size_t i = 0; i < c->host_blocks.size() && !pinned; i++) {
@@ -1359,6 +1418,7 @@ extern "C" int rtpbr_write_buffer(rtpbr_ctx* c, int which, const void* src, size
     if (int r = buf_ptr(c, which, &p, &n)) return r;
     if (!src || nbytes != n) return fail(RTPBR_EINVAL, "source size does not match the buffer");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     if (int r = rt_order_after_reads(c, 1u << which)) return r;
     HIP_TRY(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1405,6 +1465,7 @@ static void fold_shards(Counters& h) {
 extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
     if (!c || !out) return fail(RTPBR_EINVAL, "null argument");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     Counters h;
     HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1423,6 +1484,7 @@ extern "C" int rtpbr_get_counters(rtpbr_ctx* c, rtpbr_counters* out) {
 extern "C" int rtpbr_get_counter(rtpbr_ctx* c, const char* name, unsigned long long* out) {
     if (!c || !name || !out) return fail(RTPBR_EINVAL, "null argument");
     if (int r = set_dev(c)) return r;
+    if (int r = flush_shade(c)) return r;
     Counters h;
     HIP_TRY(hipMemcpyAsync(&h, c->counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1512,6 +1574,7 @@ extern "C" int rtpbr_get_stream(rtpbr_ctx* c, void** stream) {
 
 extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) {
     if (!c || !key) return fail(RTPBR_EINVAL, "null argument");
+    if (int r = flush_shade(c)) return r;
     if (!strcmp(key, "staging_bytes")) {
         if (value < (1 << 20)) return fail(RTPBR_EINVAL, "staging_bytes must be >= 1 MiB");
         c->staging_bytes = value;
@@ -1566,6 +1629,9 @@ extern "C" int rtpbr_set_option(rtpbr_ctx* c, const char* key, long long value) 
     } else if (!strcmp(key, "env_packed")) {
         if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "env_packed must be 0 (float4 texels) or 1 (RGBA8 texels + 256-entry table: 8-bit sources, same values)");
         c->env_packed = (int)value;
+    } else if (!strcmp(key, "src_lazy")) {
+        if (value < 0 || value > 1) return fail(RTPBR_EINVAL, "src_lazy must be 0 (every one-step launch shades) or 1 (the shading rides with the next launch's gen pass)");
+        c->src_lazy = (int)value;
     } else if (!strcmp(key, "split_head")) {
         if (value < -1 || value > 1) return fail(RTPBR_EINVAL, "split_head must be -1 (automatic: small frames), 0 (the heavy head fills the first groups) or 1 (interleaved: one head entry per group)");
         c->split_head = (int)value;

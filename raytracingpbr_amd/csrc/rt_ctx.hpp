@@ -22,6 +22,7 @@ void launch_src_gen(const Params& P, int kind, hipStream_t st);
 void launch_src_march(const Params& P, int kind, int grid, hipStream_t st);
 int src_march_blocks_per_cu(int kind);
 void launch_src_shade(const Params& P, int kind, hipStream_t st);
+void launch_src_shade_gen(const Params& P, int kind, bool count, hipStream_t st);      // the previous bounce-step's shading + this one's gen in one pass
 void launch_refresh(float4* ib, rtpbr_ray* rb, float2* db, float* dp, int adaptive, size_t n, hipStream_t st);
 void launch_post_process(const Params& P, hipStream_t st);
 void launch_pack(const Params& P, float4* dst, hipStream_t st);
@@ -54,6 +55,7 @@ struct RtJitModule {
     hipModule_t module = nullptr;
     hipFunction_t trace = nullptr, primary = nullptr, persistent_pool = nullptr, persistent_steps = nullptr;
     hipFunction_t chain_steps = nullptr;                                           // the chain kernel (rt_chain.hpp)
+    hipFunction_t src_shade_gen = nullptr, src_shade_gen_count = nullptr;
     hipFunction_t src_gen = nullptr, src_march = nullptr, src_shade = nullptr;      // the wavefront split of one src/ bounce-step (rt_split.hpp)
     int trace_blocks_per_cu = 0, persistent_blocks_per_cu = 0, march_blocks_per_cu = 0;
     std::string path;
@@ -181,6 +183,14 @@ struct rtpbr_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int src_split = 1;            // src/ form: launches of at most this many bounce-steps run as the wavefront split (gen / march / shade per step); 0 = never (measured at 1080p: one step 0.51 against 0.60 ms fused; two steps 1.3 against 0.65)
     int split_wait = 24;          // ... its march kernel refills when this many lanes are free
+    // LAZY SHADING of the split's launches (option src_lazy): the shading of a bounce-step is not launched with it — the next launch's gen
+    // pass does it first (src_shade_gen: one pass over ray_buffer instead of two), and anything that could see the difference flushes it
+    // (flush_shade in rt_capi.hip: readers and writers of ray_buffer, the work counters, every setter, refresh)
+    int src_lazy = 1;
+    bool shade_pending = false;
+    uint32_t shade_pending_base = 0;
+    bool shade_pending_same_call = false;      // ... of an earlier step of the rtpbr_sample() call in progress: it counts into this call's counters
+    bool ray_ptr_out = false;     // rtpbr_buffer_device_ptr handed ray_buffer out: its holder reads it unannounced, no lazy shading any more
     int split_head = -1;          // ... the list's heavy head interleaved over the groups: -1 = for small frames (two waves per SIMD), 0 never, 1 always
     uint32_t* order = nullptr;         // np x u32
     rt::PlanBuf* plan = nullptr;

@@ -500,6 +500,8 @@ int rt_jit_acquire(rtpbr_ctx* c, const RtJitKey& key, RtJitModule** out) {
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_gen, m->module, "rt_jit_src_gen");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_march, m->module, "rt_jit_src_march");
         if (e == hipSuccess) e = hipModuleGetFunction(&m->src_shade, m->module, "rt_jit_src_shade");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->src_shade_gen, m->module, "rt_jit_src_shade_gen");
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->src_shade_gen_count, m->module, "rt_jit_src_shade_gen_count");
         if (e == hipSuccess) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&m->march_blocks_per_cu, m->src_march, 256, 0);
     }
     if (e != hipSuccess) {

@@ -53,6 +53,16 @@ extern "C" __global__ void __launch_bounds__(256) rt_jit_src_gen(const Params P)
     RT_JIT_BAKE_PARAMS(Q);
     src_gen_impl<RT_JIT_KIND>(Q);
 }
+extern "C" __global__ void __launch_bounds__(256) rt_jit_src_shade_gen(const Params P) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    src_gen_impl<RT_JIT_KIND, true, false>(Q);
+}
+extern "C" __global__ void __launch_bounds__(256) rt_jit_src_shade_gen_count(const Params P) {
+    Params Q = P;
+    RT_JIT_BAKE_PARAMS(Q);
+    src_gen_impl<RT_JIT_KIND, true, true>(Q);
+}
 extern "C" __global__ void __launch_bounds__(256) rt_jit_src_march(const Params P) {
     Params Q = P;
     RT_JIT_BAKE_PARAMS(Q);

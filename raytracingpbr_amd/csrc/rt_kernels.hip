@@ -534,6 +534,18 @@ int src_march_blocks_per_cu(int kind) {
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, src_march<KIND_GENERIC>, 256, 0);
     return e == hipSuccess ? per_cu : 0;
 }
+template <bool COUNT>
+static void launch_src_shade_gen_t(const Params& P, int kind, hipStream_t st) {
+    int grid = (P.np + 255) / 256;
+    if (kind == KIND_BOXES) hipLaunchKernelGGL((src_shade_gen<KIND_BOXES, COUNT>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_BUNNY) hipLaunchKernelGGL((src_shade_gen<KIND_BUNNY, COUNT>), dim3(grid), dim3(256), 0, st, P);
+    else if (kind == KIND_MIXED) hipLaunchKernelGGL((src_shade_gen<KIND_MIXED, COUNT>), dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((src_shade_gen<KIND_GENERIC, COUNT>), dim3(grid), dim3(256), 0, st, P);
+}
+void launch_src_shade_gen(const Params& P, int kind, bool count, hipStream_t st) {
+    if (count) launch_src_shade_gen_t<true>(P, kind, st);
+    else launch_src_shade_gen_t<false>(P, kind, st);
+}
 void launch_src_shade(const Params& P, int kind, hipStream_t st) {
     int grid = (P.np + 255) / 256;
     if (kind == KIND_BOXES) hipLaunchKernelGGL((src_shade<KIND_BOXES>), dim3(grid), dim3(256), 0, st, P);

@@ -24,19 +24,73 @@ enum { MS_NONE = 0, MS_MARCH = 1, MS_HIT = 2, MS_MISS = 3 };
 // march word of a local pixel: state (2 bits) | nearest object (5 bits) << 2 | RNG draws of this bounce-step so far << 8
 RT_D uint32_t mw_pack(uint32_t state, int idx, uint32_t cnt) { return state | ((uint32_t)idx << 2) | (cnt << 8); }
 
+// The rest of raytrace() (src/pathtracer.py:16-36) after the raycast of bounce-step `base` ended in `word` (MS_HIT / MS_MISS), on the
+// pixel's ray record in registers: surface interaction or environment lookup, stop tests — the state the next bounce-step starts from.
 template <int KIND>
+RT_D void src_shade_core(const Params& P, const ObjFull* lds_obj, int px, int py, uint32_t word, uint32_t base, rtpbr_ray& rb,
+                         uint32_t& n_hits, uint32_t& n_sky, uint32_t& n_samples) {
+    vec3 o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
+    vec3 d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
+    vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]);
+    const uint32_t key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, base);
+    uint32_t cnt = word >> 8;
+    // depth += 1 (scene.py:83)
+    int depth = rb.depth + 1;
+    if ((word & 3u) == MS_HIT) {
+        const ObjFull ob = lds_obj[(word >> 2) & 31u];
+        surface_interaction<KIND>(P, ob, o, o, d, col, key, cnt);
+        n_hits = 1;
+        float intensity = brightness(col);
+        col = col * mk(ob.emission[0], ob.emission[1], ob.emission[2]);
+        float visible = brightness(col);
+        bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
+        if (stop) depth = -depth;
+    } else {
+        depth = -depth;
+        col = col * sky_color(P, d);
+        n_sky = 1;
+        if (P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) col = col * (depth < -1 ? 1.0f : 0.0f);
+    }
+    n_samples = 1;
+    rb.origin[0] = o.x; rb.origin[1] = o.y; rb.origin[2] = o.z;
+    rb.direction[0] = d.x; rb.direction[1] = d.y; rb.direction[2] = d.z;
+    rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
+    rb.depth = depth;
+}
+
+// SHADE_FIRST (round 6, the lazy shading of one-step launches): the SAME pass over ray_buffer first finishes the previous bounce-step
+// (P.shade_base) — the shading the host has not launched yet — and then generates this one: one read and one write of the 40-byte ray
+// record instead of two each, one kernel instead of two (gen 39 + shade 38 us of a 430 us launch at 1080p).  The arithmetic per pixel
+// is the two kernels' in sequence.  COUNT: the shading belongs to THIS rtpbr_sample() call (an earlier step of a call of several) and
+// counts into its work counters; a shading left over from the previous call does not (nobody can ask for that call's counters any
+// more: rt_capi.hip flushes the pending shading before anything that could see it).
+template <int KIND, bool SHADE_FIRST = false, bool COUNT = false>
 RT_D void src_gen_impl(const Params& P) {
+    __shared__ ObjFull lds_obj[SHADE_FIRST ? MAX_OBJ : 1];
     zero_next_counters(P);
+    if constexpr (SHADE_FIRST) stage_objects(P, lds_obj);
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     int px = 0, py = 0;
-    bool valid = q < (uint32_t)P.np && pixel_of(P, q, px, py);
+    const bool in_frame = q < (uint32_t)P.np && pixel_of(P, q, px, py);
+    bool valid = in_frame;
     const rtpbr_config& g = P.cfg;
     const size_t pi = (size_t)px * g.height + py;
     // self-adaptive sampling mask (src/pathtracer.py:97-101)
     if (valid && g.adaptive_sampling && !(P.diff_pixels[pi] > g.noise_threshold)) valid = false;
-    uint32_t word = MS_NONE, n_samples = 0, n_dep = 0;
-    if (valid) {
+    uint32_t word = MS_NONE, n_samples = 0, n_dep = 0, n_hits = 0, n_sky = 0;
+    uint32_t old_word = MS_NONE;
+    if constexpr (SHADE_FIRST) old_word = in_frame ? P.march_out[q] : (uint32_t)MS_NONE;
+    const bool shade = SHADE_FIRST && ((old_word & 3u) == MS_HIT || (old_word & 3u) == MS_MISS);
+    if (valid || shade) {
         rtpbr_ray rb = P.ray_buffer[pi];
+        if constexpr (SHADE_FIRST) {
+            if (shade) {
+                uint32_t h_ = 0, s_ = 0, n_ = 0;
+                src_shade_core<KIND>(P, lds_obj, px, py, old_word, P.shade_base, rb, h_, s_, n_);
+                if constexpr (COUNT) n_hits = h_, n_sky = s_, n_samples = n_;
+            }
+        }
+        if (valid) {
         const uint32_t key = rng_key(g.seed, (uint32_t)px, (uint32_t)py, P.sample_base);
         uint32_t cnt = 0;
         int depth = rb.depth;
@@ -46,7 +100,7 @@ RT_D void src_gen_impl(const Params& P) {
         if (rng_next(key, cnt) > p) {
             rb.color[0] = rb.color[1] = rb.color[2] = 0.0f;
             rb.depth = -depth;
-            n_samples = 1;
+            n_samples += 1;
         } else {
             vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]) * (1.0f / p);
             // track_once :53-62
@@ -68,13 +122,14 @@ RT_D void src_gen_impl(const Params& P) {
             rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
             word = mw_pack(MS_MARCH, 0, cnt);
         }
+        }
         P.ray_buffer[pi] = rb;
     }
     if (q < (uint32_t)P.np) P.march_out[q] = word;
     // the march kernel's team counters start from zero
     if (blockIdx.x == 0)
         for (int t = threadIdx.x; t < P.n_teams; t += blockDim.x) P.team_counter[t * 16] = 0u;
-    flush_counters(P, 0, 0, 0, 0, n_samples, n_dep);
+    flush_counters(P, 0, 0, n_hits, n_sky, n_samples, n_dep);
 }
 
 // One entry of the march list as the march kernel stages it: local pixel, frame index, march word, ray
@@ -394,33 +449,7 @@ RT_D void src_shade_impl(const Params& P) {
         pixel_of(P, q, px, py);
         const size_t pi = (size_t)px * P.cfg.height + py;
         rtpbr_ray rb = P.ray_buffer[pi];
-        vec3 o = mk(rb.origin[0], rb.origin[1], rb.origin[2]);
-        vec3 d = mk(rb.direction[0], rb.direction[1], rb.direction[2]);
-        vec3 col = mk(rb.color[0], rb.color[1], rb.color[2]);
-        const uint32_t key = rng_key(P.cfg.seed, (uint32_t)px, (uint32_t)py, P.sample_base);
-        uint32_t cnt = word >> 8;
-        // raytrace() src/pathtracer.py:16-36 after raycast(); depth += 1 (scene.py:83)
-        int depth = rb.depth + 1;
-        if (st == MS_HIT) {
-            const ObjFull ob = lds_obj[(word >> 2) & 31u];
-            surface_interaction<KIND>(P, ob, o, o, d, col, key, cnt);
-            n_hits = 1;
-            float intensity = brightness(col);
-            col = col * mk(ob.emission[0], ob.emission[1], ob.emission[2]);
-            float visible = brightness(col);
-            bool stop = intensity < visible || visible < P.cfg.vis_lo || visible > P.cfg.vis_hi;
-            if (stop) depth = -depth;
-        } else {
-            depth = -depth;
-            col = col * sky_color(P, d);
-            n_sky = 1;
-            if (P.cfg.primary_miss == RTPBR_PRIMARY_BLACK) col = col * (depth < -1 ? 1.0f : 0.0f);
-        }
-        n_samples = 1;
-        rb.origin[0] = o.x; rb.origin[1] = o.y; rb.origin[2] = o.z;
-        rb.direction[0] = d.x; rb.direction[1] = d.y; rb.direction[2] = d.z;
-        rb.color[0] = col.x; rb.color[1] = col.y; rb.color[2] = col.z;
-        rb.depth = depth;
+        src_shade_core<KIND>(P, lds_obj, px, py, word, P.sample_base, rb, n_hits, n_sky, n_samples);
         P.ray_buffer[pi] = rb;
     }
     flush_counters(P, 0, 0, n_hits, n_sky, n_samples, 0);
@@ -428,6 +457,8 @@ RT_D void src_shade_impl(const Params& P) {
 
 template <int KIND>
 __global__ void __launch_bounds__(256) src_gen(const Params P) { src_gen_impl<KIND>(P); }
+template <int KIND, bool COUNT>
+__global__ void __launch_bounds__(256) src_shade_gen(const Params P) { src_gen_impl<KIND, true, COUNT>(P); }
 template <int KIND>
 __global__ void __launch_bounds__(256) src_march(const Params P) { src_march_impl<KIND>(P); }
 template <int KIND>

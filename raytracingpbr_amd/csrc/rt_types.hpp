@@ -231,6 +231,8 @@ struct Params {
     uint32_t* cost_buffer;
     unsigned int* team_counter;   // split march kernel: one claim counter per team of blocks, 64 bytes apart (zeroed by src_gen)
     int32_t n_teams;
+    uint32_t shade_base;    // src_shade_gen: the bounce-step whose shading this launch does first (the lazy shading of one-step launches; fills a hole:
+                            // a field in front of K cost the unbaked complete-path instances 4 % — scalar loads regrouped in a kernel at its register budget)
     uint32_t* march_out;    // wavefront split of the src/ form (rt_split.hpp): one word per local pixel between its three kernels
     const uint32_t* order;
     struct PlanBuf* plan;

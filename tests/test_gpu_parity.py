@@ -211,6 +211,69 @@ def test_dense_staging_equals_item_linear_records_and_the_oracle():
         assert np.array_equal(imgs[0], imgs[1]), K
 
 
+def test_lazy_shading_of_one_step_launches_is_invisible():
+    """Round 6: a one-step src/ launch leaves its shading to the next launch's gen pass (src_shade_gen: one pass over ray_buffer
+    instead of two) and everything that could see the difference flushes it first.  A script of calls that interleaves one-step
+    launches with every such observer — ray_buffer read / written / handed out, the counters, setters (camera, scene, config
+    fields, tiles-free options), refresh, post_process, fused launches, a switch of n — on the HIP path with src_lazy 1 and 0 and
+    on the oracle: ray_buffer, image_buffer and the counters agree bit for bit at every checkpoint."""
+    from raytracingpbr_amd import Camera
+    case = case_by_name("src_persistent")
+    def script(r, hip, lazy):
+        case.setup(r)
+        if hip:
+            r.set_option("src_lazy", lazy)
+        out = []
+        def check(tag, counters=True):
+            out.append((tag, bits(r.ray_buffer).copy(), bits(r.image_buffer).copy()))
+            if counters:
+                c = r.counters()
+                out.append((tag + ":ctr", (c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits)))
+        for _ in range(5): r.sample(1)                      # five launches, nothing looks in between
+        check("five")
+        for _ in range(3): r.sample(1)
+        c = r.counters(); out.append(("ctr-only", (c.samples, c.hits, c.sky_lookups)))      # the counters alone flush
+        r.sample(1); r.post_process(); r.sample(1)          # post_process does not need the shading
+        out.append(("pixels", bits(r.image_pixels).copy()))
+        check("after-post")
+        r.sample(2); r.sample(1)                            # two steps in one call, then one
+        cam = case.scene.camera
+        r.set_camera(Camera(tuple(float(x) for x in np.array(tuple(cam.lookfrom)) + np.array([0.3, 0.1, 0.0])), tuple(cam.lookat), tuple(cam.vup), cam.vfov, cam.aspect, cam.aperture, cam.focus))
+        r.sample(1); r.sample(1)
+        check("camera")
+        r.sample(1); r.refresh(); r.sample(1); r.sample(1)  # refresh must see the shaded colours (the next deposit adds them)
+        check("refresh")
+        r.sample(1)
+        rb = r.ray_buffer                                   # read, modify, write back while a shading would be pending
+        rb2 = rb.copy(); rb2[..., 6:9] *= 0.5
+        r.sample(1)
+        r.ray_buffer = rb2
+        r.sample(1); r.sample(1)
+        check("written")
+        r.sample(1); r.sample(40)                           # a fused launch after a one-step launch: that one's shading must not count here
+        c = r.counters(); out.append(("ctr-fused40", (c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits)))
+        r.sample(1); r.sample(3)                            # ... and three steps in one call: all three shadings count
+        c = r.counters(); out.append(("ctr-three", (c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits)))
+        r.sample(1)
+        check("fused")
+        if hip:
+            r.sample(1)
+            r.device_ptr(2)                                 # ray_buffer handed out: shaded now, and with every launch from here on
+        else:
+            r.sample(1)
+        r.sample(1); r.sample(1)
+        check("handed-out")
+        return out
+    o = script(OracleRenderer(case.scene, case.cfg), False, 0)
+    for lazy in (1, 0):
+        g = script(Renderer(case.scene, case.cfg), True, lazy)
+        assert len(g) == len(o)
+        for a, b in zip(g, o):
+            assert a[0] == b[0]
+            for x, y in zip(a[1:], b[1:]):
+                assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y, (lazy, a[0])
+
+
 def test_timing_option_only_removes_the_events():
     """Option timing = 0: rtpbr_sample() records no HIP events (bench.py times its small launches that way) — same bits in both
     kernel forms, rtpbr_last_sample_ms / rtpbr_last_primary_ms answer ESTATE until a timed call has run, and a timed call reports
