@@ -274,6 +274,50 @@ def test_lazy_shading_of_one_step_launches_is_invisible():
                 assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y, (lazy, a[0])
 
 
+def test_lazy_shading_random_call_sequences():
+    """Random sequences of API calls around one-step launches — launches of 1 / 2 / 40 steps, post_process, refresh, reads of every
+    buffer, the counters, camera / option / scene setters, ray_buffer written back — with src_lazy 1 against src_lazy 0: everything
+    observed is identical, observation by observation (the flush hooks of rt_capi.hip)."""
+    from raytracingpbr_amd import Camera
+    case = case_by_name("src_persistent")
+    cam = case.scene.camera
+    def run(seed, lazy):
+        rng = np.random.default_rng(seed)
+        r = Renderer(case.scene, case.cfg)
+        case.setup(r)
+        r.set_option("src_lazy", lazy)
+        seen = []
+        for _ in range(70):
+            op = int(rng.integers(0, 14))
+            if op <= 4: r.sample(1)
+            elif op == 5: r.sample(2)
+            elif op == 6: r.sample(40)
+            elif op == 7: r.post_process(); seen.append(bits(r.image_pixels).copy())
+            elif op == 8: r.refresh()
+            elif op == 9: seen.append(bits(r.ray_buffer).copy())
+            elif op == 10:
+                c = r.counters(); seen.append((c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits))
+            elif op == 11:
+                d = rng.uniform(-0.2, 0.2, 3)
+                r.set_camera(Camera(tuple(float(x) for x in np.array(tuple(cam.lookfrom)) + d), tuple(cam.lookat), tuple(cam.vup), cam.vfov, cam.aspect, cam.aperture, cam.focus))
+            elif op == 12:
+                k = int(rng.integers(0, 3))
+                if k == 0: r.set_option("split_wait", int(rng.integers(1, 40)))
+                elif k == 1: r.set_scene(case.scene)
+                else: seen.append(bits(r.image_buffer).copy())
+            else:
+                rb = r.ray_buffer; rb[..., 6:9] *= np.float32(0.75); r.ray_buffer = rb
+        seen.append(bits(r.ray_buffer).copy()); seen.append(bits(r.image_buffer).copy())
+        c = r.counters(); seen.append((c.samples, c.raycasts, c.march_steps, c.hits, c.sky_lookups, c.deposits))
+        r.close()
+        return seen
+    for seed in range(6):
+        a, b = run(seed, 1), run(seed, 0)
+        assert len(a) == len(b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y, (seed, i)
+
+
 def test_timing_option_only_removes_the_events():
     """Option timing = 0: rtpbr_sample() records no HIP events (bench.py times its small launches that way) — same bits in both
     kernel forms, rtpbr_last_sample_ms / rtpbr_last_primary_ms answer ESTATE until a timed call has run, and a timed call reports
